@@ -1,0 +1,241 @@
+/*
+ * sfk.h -- C ABI of libsfk.so: the MI355X (gfx950) kernels behind the SlowFast training hot path.
+ *
+ * The reference (zc402/video-classification) has no FFI of its own: its hot path is
+ *   train.py:216-252   Trainer.train_epoch  (forward, CrossEntropyLoss, backward, Adam)
+ *   model/my_slowfast.py:44-126,260-344     model construction + lateral fusion forward
+ * and every device kernel is launched implicitly by torch.nn modules.  Each entry point below replaces one
+ * such implicit operator class; the comment above it names the reference construction site (file:line) and
+ * the torch.nn semantics it must reproduce.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs.  No torch / C++ types cross this boundary.
+ *   - every buffer (inputs, outputs, workspaces) is owned by the caller; nothing is allocated, freed or
+ *     retained past the call.  All pointers are DEVICE pointers unless a comment says "host".
+ *   - calls are asynchronous on the caller's hipStream_t (passed as void*), never synchronise, and are
+ *     safe to capture into a hipGraph.  No global mutable state.
+ *   - return value: SFK_OK or a negative sfk_status; no exceptions, no abort.
+ *   - feature maps are CHANNELS-LAST in HBM: element (n,t,h,w,c) of an sfk_fmap lives at
+ *         ptr[ (((n*T + t)*H + h)*W + w) * ld + c_off + c ]
+ *     `ld` (elements between consecutive pixels) >= c_off + c lets a producer write straight into a slice of
+ *     a wider buffer -- this is how torch.cat([x_slow, fuse], 1) (my_slowfast.py:343) is eliminated.
+ *   - dtype: SFK_BF16 (storage bf16, fp32 accumulate; the benchmark precision) or SFK_F32 (storage fp32,
+ *     exact-fp32 MFMA; the parity precision).  Statistics, master weights and gradients are always fp32.
+ */
+#ifndef SFK_H
+#define SFK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFK_ABI_VERSION 1
+#define SFK_MAX_TAPS 16
+
+typedef void* sfk_stream_t; /* hipStream_t */
+
+typedef enum {
+  SFK_OK = 0,
+  SFK_ERR_INVALID = -1,     /* null pointer, non-positive extent, inconsistent descriptor   */
+  SFK_ERR_UNSUPPORTED = -2, /* alignment / size outside what the kernels handle            */
+  SFK_ERR_LAUNCH = -3       /* hipGetLastError() after the launch was not hipSuccess        */
+} sfk_status;
+
+typedef enum { SFK_F32 = 0, SFK_BF16 = 1 } sfk_dtype;
+
+typedef struct {
+  void* ptr;
+  int32_t dtype;         /* sfk_dtype */
+  int32_t n, t, h, w, c; /* logical extents */
+  int32_t ld;            /* elements between consecutive pixels (>= c_off + c) */
+  int32_t c_off;         /* first channel of this map inside the pixel record  */
+} sfk_fmap;
+
+/* One filter tap of an implicit-GEMM pass: the gathered pixel is  row*gs + (dt,dh,dw);  `widx` selects the
+ * [cin] slice of the filter row  w[co][widx][:]. */
+typedef struct {
+  int8_t dt, dh, dw;
+  uint8_t widx;
+} sfk_tap;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * sfk_conv_igemm -- Conv3d forward AND data-gradient as one implicit GEMM on MFMA.
+ * Replaces: every nn.Conv3d the path constructs -- stems (my_slowfast.py:63-65), bottleneck conv_a/b/c and
+ * branch1 shortcuts (pytorchvideo create_res_stage, called via my_slowfast.py:94-125), lateral fusion conv
+ * (my_slowfast.py:195-202) -- and their autograd input gradients (train.py:230).
+ *
+ * Row space: rows m = (n, rt, rh, rw), n < x.n.  For each row and output channel co < cout:
+ *     acc = sum_{tap < ntaps} sum_{ci < cin}  X[n, rt*gs[0]+dt, rh*gs[1]+dh, rw*gs[2]+dw, ci] * w[co][widx][ci]
+ *   (pixels outside x's extents read as zero = the conv's zero padding), then
+ *     Y[n, rt*os[0]+oo[0], rh*os[1]+oo[1], rw*os[2]+oo[2], co]  (=|+=)  acc      (+= when `accumulate`).
+ *   forward conv, stride s, pad p:  gs = s, tap.d = k - p, os = 1, oo = 0, rows = output pixels.
+ *   data gradient, stride 1:        x = dY, gs = 1, tap.d = p - k, w = filters with (co,ci) swapped.
+ *   data gradient, stride > 1:      one pass per output-parity class: os = s, oo = class offset, taps = the taps
+ *                                   of that class (see video-classification_amd/plan.py).
+ * `stats` (optional): per row-tile partial sums of acc and acc^2 per channel, laid out [mtiles][cout][2],
+ *   mtiles = sfk_conv_igemm_mtiles(desc).  They feed sfk_bn_finalize, so BatchNorm3d's batch statistics
+ *   (my_slowfast.py:215-222; pytorchvideo norm_a/b/c) cost no extra pass over the conv output.
+ * Requirements: x.dtype == y.dtype; cin % (16/sizeof(dtype)) == 0, likewise x.ld, x.c_off; cout % 4 == 0,
+ *   y.ld % 4 == 0, y.c_off % 4 == 0; 16-byte aligned base pointers.
+ */
+typedef struct {
+  sfk_fmap x, y;
+  int32_t rt, rh, rw;
+  int32_t gs[3], os[3], oo[3];
+  int32_t ntaps;
+  sfk_tap taps[SFK_MAX_TAPS];
+  const void* w; /* [cout][wtaps][cin], dtype of x */
+  int32_t wtaps, cin, cout;
+  int32_t accumulate;
+  float* stats;
+} sfk_conv_desc;
+
+int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream);
+int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats; <0 on error */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * sfk_conv_wgrad -- Conv3d filter gradient (autograd of the same nn.Conv3d modules, train.py:230).
+ *   dw[co][widx][ci] += sum_rows dY[n,rt,rh,rw,co] * X[n, rt*gs[0]+dt, rh*gs[1]+dh, rw*gs[2]+dw, ci]
+ * rows = the pixels of dy (dy.t/h/w are the row extents).  dw is fp32 and is ACCUMULATED into with float
+ * atomics (zero it once per step with sfk_fill_zero).  Same alignment rules as sfk_conv_igemm.
+ */
+typedef struct {
+  sfk_fmap x, dy;
+  int32_t gs[3];
+  int32_t ntaps;
+  sfk_tap taps[SFK_MAX_TAPS];
+  float* dw; /* [cout][wtaps][cin] fp32 */
+  int32_t wtaps, cin, cout;
+} sfk_wgrad_desc;
+
+int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * sfk_stem_im2col -- gathers the stem's (kh x kw x cin) spatial window of every output pixel into a
+ * channels-last patch matrix, reading the clip tensor in place with arbitrary element strides.
+ * Replaces: the permute / channel-slice views of _prepare_slowfast_data (train.py:136-140), PackPathway's
+ * frame gather ((deprecated)/(torchvideo)train.py:60-71) and the input side of the stem Conv3d
+ * (my_slowfast.py:64-65).  The temporal taps of the stem (kt = 1 or 5) are applied afterwards by
+ * sfk_conv_igemm on the patch matrix.
+ *   out[n,t,ho,wo, (kh*KW + kw)*cin + ci] = src[n, ci, frame(t), ho*sh - ph + kh, wo*sw - pw + kw]  (0 outside)
+ *   frame(t) = t_index ? t_index[t] : t;  columns >= KH*KW*cin of `out` (padding up to out.c) are zeroed.
+ * src element (n,ci,t,h,w) is at src[n*sn + ci*sc + t*st + h*sh_ + w*sw_]  (element strides).
+ */
+typedef struct {
+  const void* src;
+  int32_t src_dtype; /* SFK_F32 or SFK_BF16 */
+  int64_t sn, sc, st, sh, sw;
+  int32_t cin, t_in, h_in, w_in;
+  const int32_t* t_index; /* device, out.t entries, or NULL */
+  int32_t kh, kw, stride_h, stride_w, pad_h, pad_w;
+  sfk_fmap out; /* (n, t_out, ho, wo, c >= kh*kw*cin) */
+} sfk_im2col_desc;
+
+int sfk_stem_im2col(const sfk_im2col_desc* d, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * BatchNorm3d (eps, momentum; affine; running stats) -- nn.BatchNorm3d after every conv
+ * (my_slowfast.py:143-146,215-222; pytorchvideo stems / bottlenecks), ReLU (nn.ReLU), the residual
+ * add of pytorchvideo ResBlock and their autograd.  All per-channel vectors are fp32.
+ */
+
+/* Training forward, step 1: reduce `nparts` partial (sum, sumsq) rows -> batch mean / biased var; writes
+ * mean, invstd, the fused scale = gamma*invstd and shift = beta - mean*scale, and updates
+ * running_mean/var (unbiased var, momentum) and num_batches_tracked exactly as nn.BatchNorm3d does. */
+int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                    sfk_stream_t stream);
+
+/* Eval forward: scale/shift from the running statistics. */
+int sfk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int32_t c, float* scale, float* shift,
+                       sfk_stream_t stream);
+
+/* Partial (sum, sumsq) of a feature map when no conv epilogue produced them: partials[nparts][c][2];
+ * returns nparts through *nparts_out (host), at most `max_parts`. */
+int sfk_bn_stats(const sfk_fmap* y, float* partials, int32_t max_parts, int32_t* nparts_out,
+                 sfk_stream_t stream);
+
+/* a = act( y*scale + shift + shortcut ),  shortcut = 0 | res | res*res_scale + res_shift ; act = ReLU if relu.
+ * (stem / bottleneck norm+act, ResBlock "x + branch2(x)" then ReLU.) */
+int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
+                 const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
+                 sfk_stream_t stream);
+
+/* Backward of a = act(bn(y) [+ shortcut]) given dA:
+ *   dz = dA * mask,   mask = (mask_src > 0) if mask_src, else (y*scale+shift > 0) if relu, else 1
+ *   reduce: partials[nparts][c][2] = (sum dz, sum dz*xhat), xhat = (y-mean)*invstd; if dz_out: dz_out = dz
+ *   finalize: dgamma (+)= sum dz*xhat, dbeta (+)= sum dz; coef[c][3] = (gamma*invstd, sum dz/count, sum dz*xhat/count)
+ *   apply: dy = coef0 * (dz - coef1 - xhat*coef2)
+ */
+int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, int32_t relu,
+                      const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
+                      sfk_stream_t stream);
+int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
+                        const float* invstd, float* dgamma, float* dbeta, float* coef, sfk_stream_t stream);
+int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
+                     const float* invstd, const float* scale, const float* shift, int32_t relu,
+                     const float* coef, const sfk_fmap* dy, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * MaxPool3d (1,k,k)/(1,s,s)/(0,p,p) of the stems (my_slowfast.py:66-68).  `argmax` (uint8 per output
+ * element: kh*k + kw of the first maximum in torch's scan order) makes the backward tie-exact. */
+int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* argmax, int32_t k, int32_t s, int32_t p,
+                    sfk_stream_t stream);
+int sfk_maxpool_bwd(const sfk_fmap* dy, const uint8_t* argmax, const sfk_fmap* dx, int32_t k, int32_t s,
+                    int32_t p, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Head: AvgPool3d(kernel, stride 1) per pathway -> concat -> Dropout(p) -> Linear at every position ->
+ * global mean (my_slowfast.py:75; pytorchvideo PoolConcatPathway + ResNetBasicHead).  By linearity
+ *   feat[n, f_off + c] = (1/P) sum_{positions p} keep(n,c,p)/(1-rate) * mean_{window(p)} x[n, :, c]
+ *   logits = feat @ W^T + b
+ * keep() is a counter-based hash of (seed, n, feature index, p): stateless, so the backward regenerates it.
+ * rate == 0 -> eval.  feat is fp32 [n][feat_ld].  seed is read from device memory (graph-replay safe). */
+int sfk_head_pool_fwd(const sfk_fmap* x, int32_t kt, int32_t kh, int32_t kw, float rate,
+                      const uint64_t* seed, float* feat, int32_t feat_ld, int32_t f_off, sfk_stream_t stream);
+int sfk_head_pool_bwd(const float* dfeat, int32_t feat_ld, int32_t f_off, int32_t kt, int32_t kh, int32_t kw,
+                      float rate, const uint64_t* seed, const sfk_fmap* dx, sfk_stream_t stream);
+/* the keep mask itself, for tests: mask[n][c][P] uint8 */
+int sfk_head_dropout_mask(int32_t n, int32_t c, int32_t f_off, int32_t positions, float rate,
+                          const uint64_t* seed, uint8_t* mask, sfk_stream_t stream);
+
+/* nn.Linear(2304, num_class) of the head, fp32.  logits[n][k] = feat[n] . w[k] + b[k] */
+int sfk_fc_fwd(const float* feat, const float* w, const float* b, float* logits, int32_t n, int32_t f,
+               int32_t k, sfk_stream_t stream);
+/* dfeat = dlogits @ w ; dw += dlogits^T @ feat ; db += sum_n dlogits */
+int sfk_fc_bwd(const float* dlogits, const float* feat, const float* w, float* dfeat, float* dw, float* db,
+               int32_t n, int32_t f, int32_t k, sfk_stream_t stream);
+
+/* nn.CrossEntropyLoss (mean) + argmax bookkeeping of train.py:228,239-242 in one kernel.
+ * loss_sum[0] += mean CE of this batch; correct[0] += #(argmax == label); dlogits = (softmax - onehot)/n * gscale */
+int sfk_softmax_ce(const float* logits, const int64_t* labels, int32_t n, int32_t k, float gscale,
+                   float* dlogits, float* loss_out, float* loss_sum, int32_t* correct, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * optim.Adam(lr, betas, eps, weight_decay=0) (train.py:182,231) over one flat fp32 parameter arena.
+ * step[0] is incremented on device first (bias correction uses it).  grad_scale multiplies g (1/world).
+ * If shadow != NULL also writes the compute-precision copy of the updated parameters (bf16 or f32). */
+int sfk_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+             float eps, float grad_scale, int64_t* step, void* shadow, int32_t shadow_dtype,
+             sfk_stream_t stream);
+
+/* dst[ci][widx][co] = src[co][widx][ci]  (filters for the data-gradient pass), with dtype cast. */
+int sfk_filter_transpose(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int32_t cout,
+                         int32_t wtaps, int32_t cin, sfk_stream_t stream);
+int sfk_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count,
+             sfk_stream_t stream);
+int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream);
+
+int sfk_abi_version(void);
+const char* sfk_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFK_H */

@@ -136,7 +136,7 @@ def mini_slowfast(num_class: int = 7, *, ref_style: bool = True, depth: int = 18
             stage_conv_a_kernel_sizes=(((1, 1, 1), (1, 1, 1), t3, t3), (t3,) * 4),
             head_pool_kernel_sizes=hp)
     ic = (3, 3) if input_channels is None else tuple(input_channels)
-    hp = ((1, 2, 2), (4, 2, 2)) if head_pool is None else head_pool
+    hp = ((2, 2, 2), (8, 2, 2)) if head_pool is None else head_pool
     return pv.create_slowfast(model_depth=depth, model_num_class=num_class, input_channels=ic,
                               head_pool_kernel_sizes=hp)
 

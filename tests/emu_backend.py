@@ -1,0 +1,362 @@
+"""TEST INFRASTRUCTURE: a torch-CPU restatement of the C-ABI contract of include/sfk.h.
+
+Same method surface as video_classification_amd._lib.HipBackend, so
+  * on CPU the planner (plan.py) and the whole engine schedule (engine.py) are checked against the oracle's
+    autograd without a GPU, and
+  * on the GPU box every HIP entry point is compared with this restatement on identical inputs.
+It is never imported by the product package.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from video_classification_amd._lib import ConvPass, FMap, Im2col, WgradPass
+
+
+def _tile_bm(cout: int) -> int:
+    return 128 if cout > 64 else 256
+
+
+def _gather(X: torch.Tensor, rows, gs, tap):
+    """X (N,T,H,W,C) float -> (N,rt,rh,rw,C) gathered at r*gs + d with zero padding."""
+    idx = []
+    mask = None
+    for axis, (r, g, d, ext) in enumerate(zip(rows, gs, tap[:3], X.shape[1:4])):
+        i = torch.arange(r) * g + d
+        ok = (i >= 0) & (i < ext)
+        idx.append(i.clamp(0, ext - 1))
+        shape = [1, 1, 1, 1, 1]
+        shape[axis + 1] = r
+        m = ok.view(shape)
+        mask = m if mask is None else (mask & m)
+    out = X[:, idx[0]][:, :, idx[1]][:, :, :, idx[2]]
+    return out * mask.to(out.dtype)
+
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def keep_mask(seed: int, n: int, c: int, f_off: int, positions: int, rate: float) -> np.ndarray:
+    """keep[n][c][p] exactly as csrc/pool_head.hip::keep_of."""
+    if rate <= 0:
+        return np.ones((n, c, positions), dtype=bool)
+    ni = np.arange(n, dtype=np.uint64).reshape(n, 1, 1)
+    fi = (np.arange(c, dtype=np.uint64) + np.uint64(f_off)).reshape(1, c, 1)
+    pi = np.arange(positions, dtype=np.uint64).reshape(1, 1, positions)
+    key = (ni << np.uint64(40)) ^ (fi << np.uint64(20)) ^ pi
+    r = _splitmix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(key)) >> np.uint64(40)
+    u = r.astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return u >= np.float32(rate)
+
+
+class EmuBackend:
+    name = "emu"
+
+    # ------------------------------------------------------------------ convolution
+    def conv_igemm_mtiles(self, p: ConvPass) -> int:
+        m = p.x.n * p.rows[0] * p.rows[1] * p.rows[2]
+        bm = _tile_bm(p.cout)
+        return (m + bm - 1) // bm
+
+    def conv_igemm(self, p: ConvPass):
+        def run(stream):
+            X = p.x.view5().float()
+            Wf = p.w[: p.cout * p.wtaps * p.cin].view(p.cout, p.wtaps, p.cin).float()
+            acc = torch.zeros(p.x.n, *p.rows, p.cout)
+            for tap in p.taps:
+                acc += torch.einsum("nthwc,oc->nthwo", _gather(X, p.rows, p.gs, tap), Wf[:, tap[3], :])
+            Y = p.y.view5()
+            sl = tuple(slice(o, o + (r - 1) * s + 1, s) for o, s, r in zip(p.oo, p.os, p.rows))
+            dest = Y[:, sl[0], sl[1], sl[2]]
+            if p.accumulate:
+                dest.copy_((dest.float() + acc).to(Y.dtype))
+            else:
+                dest.copy_(acc.to(Y.dtype))
+            if p.stats is not None:
+                flat = acc.reshape(-1, p.cout)
+                bm = _tile_bm(p.cout)
+                mt = (flat.shape[0] + bm - 1) // bm
+                st = p.stats[: mt * p.cout * 2].view(mt, p.cout, 2)
+                for i in range(mt):
+                    blk = flat[i * bm:(i + 1) * bm]
+                    st[i, :, 0] = blk.sum(0)
+                    st[i, :, 1] = (blk * blk).sum(0)
+        return run
+
+    def conv_wgrad(self, p: WgradPass):
+        def run(stream):
+            X = p.x.view5().float()
+            dY = p.dy.view5().float()
+            rows = (p.dy.t, p.dy.h, p.dy.w)
+            dw = p.dw[: p.cout * p.wtaps * p.cin].view(p.cout, p.wtaps, p.cin)
+            for tap in p.taps:
+                dw[:, tap[3], :] += torch.einsum("nthwo,nthwc->oc", dY, _gather(X, rows, p.gs, tap))
+        return run
+
+    def stem_im2col(self, p: Im2col):
+        def run(stream):
+            src = p.src.float()
+            if p.t_index is not None:
+                src = src.index_select(2, p.t_index.long())
+            n, c, t, h, w = src.shape
+            o = p.out
+            xp = torch.nn.functional.pad(src, (p.pad[1], p.pad[1], p.pad[0], p.pad[0]))
+            cols = torch.zeros(n, t, o.h, o.w, o.c)
+            for kh in range(p.kh):
+                for kw in range(p.kw):
+                    patch = xp[:, :, :, kh:kh + (o.h - 1) * p.stride[0] + 1:p.stride[0],
+                               kw:kw + (o.w - 1) * p.stride[1] + 1:p.stride[1]]      # n c t ho wo
+                    base = (kh * p.kw + kw) * c
+                    cols[..., base:base + c] = patch.permute(0, 2, 3, 4, 1)
+            o.view5().copy_(cols.to(o.dtype))
+        return run
+
+    # ------------------------------------------------------------------ batch norm
+    def bn_finalize(self, partials, nparts, c, count, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale,
+                    shift):
+        def run(stream):
+            pt = partials[: nparts * c * 2].view(nparts, c, 2).double().sum(0)
+            mu = pt[:, 0] / count
+            var = (pt[:, 1] / count - mu * mu).clamp_min(0)
+            is_ = (1.0 / torch.sqrt(var + eps)).float()
+            mean[:c] = mu.float()
+            invstd[:c] = is_
+            scale[:c] = gamma[:c] * is_
+            shift[:c] = beta[:c] - mu.float() * scale[:c]
+            if rm is not None:
+                unb = var * count / (count - 1) if count > 1 else var
+                rm[:c] = (1 - momentum) * rm[:c] + momentum * mu.float()
+                rv[:c] = (1 - momentum) * rv[:c] + momentum * unb.float()
+            if nbt is not None:
+                nbt.add_(1)
+        return run
+
+    def bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift):
+        def run(stream):
+            is_ = 1.0 / torch.sqrt(rv[:c] + eps)
+            scale[:c] = gamma[:c] * is_
+            shift[:c] = beta[:c] - rm[:c] * scale[:c]
+        return run
+
+    def bn_stats(self, y: FMap, partials, max_parts):
+        def run(stream):
+            v = y.view5().float().reshape(-1, y.c)
+            pt = partials[: y.c * 2].view(1, y.c, 2)
+            pt[0, :, 0] = v.sum(0)
+            pt[0, :, 1] = (v * v).sum(0)
+        return run, 1
+
+    def bn_apply(self, y, scale, shift, res, res_scale, res_shift, relu, out):
+        def run(stream):
+            c = y.c
+            v = y.view5().float() * scale[:c] + shift[:c]
+            if res is not None:
+                r = res.view5().float()
+                if res_scale is not None:
+                    r = r * res_scale[:c] + res_shift[:c]
+                v = v + r
+            if relu:
+                v = v.clamp_min(0)
+            out.view5().copy_(v.to(out.dtype))
+        return run
+
+    @staticmethod
+    def _dz(da, y, mask_src, scale, shift, relu):
+        c = y.c
+        dz = da.view5().float()
+        yv = y.view5().float()
+        if mask_src is not None:
+            dz = dz * (mask_src.view5().float() > 0)
+        elif relu:
+            dz = dz * ((yv * scale[:c] + shift[:c]) > 0)
+        return dz, yv
+
+    def bn_bwd_reduce(self, da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts):
+        def run(stream):
+            c = y.c
+            dz, yv = self._dz(da, y, mask_src, scale, shift, relu)
+            xhat = (yv - mean[:c]) * invstd[:c]
+            pt = partials[: c * 2].view(1, c, 2)
+            pt[0, :, 0] = dz.reshape(-1, c).sum(0)
+            pt[0, :, 1] = (dz * xhat).reshape(-1, c).sum(0)
+            if dz_out is not None:
+                dz_out.view5().copy_(dz.to(dz_out.dtype))
+        return run, 1
+
+    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef):
+        def run(stream):
+            pt = partials[: nparts * c * 2].view(nparts, c, 2).double().sum(0)
+            if dgamma is not None:
+                dgamma[:c] += pt[:, 1].float()
+            if dbeta is not None:
+                dbeta[:c] += pt[:, 0].float()
+            cf = coef[: c * 3].view(c, 3)
+            cf[:, 0] = gamma[:c] * invstd[:c]
+            cf[:, 1] = (pt[:, 0] / count).float()
+            cf[:, 2] = (pt[:, 1] / count).float()
+        return run
+
+    def bn_bwd_apply(self, da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy):
+        def run(stream):
+            c = y.c
+            dz, yv = self._dz(da, y, mask_src, scale, shift, relu)
+            cf = coef[: c * 3].view(c, 3)
+            xhat = (yv - mean[:c]) * invstd[:c]
+            dy.view5().copy_((cf[:, 0] * (dz - cf[:, 1] - xhat * cf[:, 2])).to(dy.dtype))
+        return run
+
+    # ------------------------------------------------------------------ pooling / head / loss
+    def maxpool_fwd(self, x, y, argmax, k, s, p):
+        def run(stream):
+            X = x.view5().float()
+            best = torch.full((x.n, x.t, y.h, y.w, x.c), -float("inf"))
+            arg = torch.zeros((x.n, x.t, y.h, y.w, x.c), dtype=torch.uint8)
+            seen = torch.zeros((1, 1, y.h, y.w, 1), dtype=torch.bool)
+            for kh in range(k):
+                for kw in range(k):
+                    tap = (0, kh - p, kw - p, 0)
+                    hi = torch.arange(y.h) * s - p + kh
+                    wi = torch.arange(y.w) * s - p + kw
+                    ok = ((hi >= 0) & (hi < x.h)).view(1, 1, -1, 1, 1) & ((wi >= 0) & (wi < x.w)).view(1, 1, 1, -1, 1)
+                    v = _gather(X, (x.t, y.h, y.w), (1, s, s), tap)
+                    take = ok & ((~seen) | (v > best) | torch.isnan(v))
+                    best = torch.where(take, v, best)
+                    arg = torch.where(take, torch.tensor(kh * k + kw, dtype=torch.uint8), arg)
+                    seen = seen | ok
+            y.view5().copy_(best.to(y.dtype))
+            argmax[: arg.numel()].view_as(arg).copy_(arg)
+        return run
+
+    def maxpool_bwd(self, dy, argmax, dx, k, s, p):
+        def run(stream):
+            G = dy.view5().float()
+            arg = argmax[: G.numel()].view(G.shape)
+            out = torch.zeros(dx.n, dx.t, dx.h, dx.w, dx.c)
+            for kh in range(k):
+                for kw in range(k):
+                    sel = (arg == kh * k + kw)
+                    for ho in range(dy.h):
+                        hi = ho * s - p + kh
+                        if not (0 <= hi < dx.h):
+                            continue
+                        for wo in range(dy.w):
+                            wi = wo * s - p + kw
+                            if 0 <= wi < dx.w:
+                                out[:, :, hi, wi] += G[:, :, ho, wo] * sel[:, :, ho, wo]
+            dx.view5().copy_(out.to(dx.dtype))
+        return run
+
+    @staticmethod
+    def _positions(x, k):
+        return (x.t - k[0] + 1, x.h - k[1] + 1, x.w - k[2] + 1)
+
+    def head_pool_fwd(self, x, k, rate, seed, feat, feat_ld, f_off):
+        def run(stream):
+            X = x.view5().float().permute(0, 4, 1, 2, 3)                      # n c t h w
+            pooled = torch.nn.functional.avg_pool3d(X, tuple(k), stride=1)   # n c pt ph pw
+            n, c = pooled.shape[:2]
+            P = pooled[0, 0].numel()
+            pooled = pooled.reshape(n, c, P)
+            if rate > 0:
+                keep = torch.from_numpy(keep_mask(int(seed[0]), n, c, f_off, P, rate))
+                pooled = pooled * keep / (1.0 - rate)
+            feat[: n * feat_ld].view(n, feat_ld)[:, f_off:f_off + c] = pooled.mean(2)
+        return run
+
+    def head_pool_bwd(self, dfeat, feat_ld, f_off, k, rate, seed, dx):
+        def run(stream):
+            n, c = dx.n, dx.c
+            pt, ph, pw = self._positions(dx, k)
+            P = pt * ph * pw
+            g = dfeat[: n * feat_ld].view(n, feat_ld)[:, f_off:f_off + c]   # n c
+            w = torch.ones(n, c, P)
+            if rate > 0:
+                w = torch.from_numpy(keep_mask(int(seed[0]), n, c, f_off, P, rate)).float() / (1.0 - rate)
+            w = (w * g.unsqueeze(2) / P).view(n, c, pt, ph, pw)
+            # adjoint of avg_pool3d(stride 1)
+            ones = torch.ones(c, 1, *k) / float(k[0] * k[1] * k[2])
+            full = torch.nn.functional.conv_transpose3d(w, ones, groups=c)   # n c t h w
+            dx.view5().copy_(full.permute(0, 2, 3, 4, 1).to(dx.dtype))
+        return run
+
+    def head_dropout_mask(self, n, c, f_off, positions, rate, seed, mask):
+        def run(stream):
+            m = keep_mask(int(seed[0]), n, c, f_off, positions, rate)
+            mask[: m.size].view(n, c, positions).copy_(torch.from_numpy(m.astype(np.uint8)))
+        return run
+
+    def fc_fwd(self, feat, w, b, logits, n, f, k):
+        def run(stream):
+            out = feat[: n * f].view(n, f) @ w[: k * f].view(k, f).t()
+            if b is not None:
+                out = out + b[:k]
+            logits.view(-1)[: n * k].copy_(out.reshape(-1))
+        return run
+
+    def fc_bwd(self, dlogits, feat, w, dfeat, dw, db, n, f, k):
+        def run(stream):
+            dl = dlogits.reshape(-1)[: n * k].view(n, k)
+            if dfeat is not None:
+                dfeat[: n * f].view(n, f).copy_(dl @ w[: k * f].view(k, f))
+            if dw is not None:
+                dw[: k * f].view(k, f).add_(dl.t() @ feat[: n * f].view(n, f))
+                if db is not None:
+                    db[:k].add_(dl.sum(0))
+        return run
+
+    def softmax_ce(self, logits, labels, n, k, gscale, dlogits, loss_out, loss_sum, correct):
+        def run(stream):
+            lg = logits.reshape(-1)[: n * k].view(n, k)
+            lsm = torch.log_softmax(lg, 1)
+            loss = -lsm[torch.arange(n), labels[:n]].sum() / n
+            if dlogits is not None:
+                d = torch.softmax(lg, 1)
+                d[torch.arange(n), labels[:n]] -= 1
+                dlogits.reshape(-1)[: n * k].copy_((d / n * gscale).reshape(-1))
+            if loss_out is not None:
+                loss_out[0] += loss
+            if loss_sum is not None:
+                loss_sum[0] += loss
+            if correct is not None:
+                correct[0] += int((lg.argmax(1) == labels[:n]).sum())
+        return run
+
+    # ------------------------------------------------------------------ optimiser / misc
+    def adam(self, p, g, m, v, count, lr, b1, b2, eps, gscale, step, shadow=None):
+        def run(stream):
+            step.add_(1)
+            t = int(step[0])
+            gg = g[:count] * gscale
+            m[:count].mul_(b1).add_(gg, alpha=1 - b1)
+            v[:count].mul_(b2).addcmul_(gg, gg, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            denom = v[:count].sqrt() / (bc2 ** 0.5) + eps
+            p[:count].addcdiv_(m[:count], denom, value=-lr / bc1)
+            if shadow is not None:
+                shadow[:count].copy_(p[:count])
+        return run
+
+    def filter_transpose(self, src, dst, cout, wtaps, cin):
+        def run(stream):
+            n = cout * wtaps * cin
+            dst[:n].view(cin, wtaps, cout).copy_(src[:n].view(cout, wtaps, cin).permute(2, 1, 0))
+        return run
+
+    def cast(self, src, dst, count):
+        def run(stream):
+            dst[:count].copy_(src[:count])
+        return run
+
+    def fill_zero(self, t):
+        def run(stream):
+            t.zero_()
+        return run

@@ -1,0 +1,189 @@
+"""The engine's forward/backward SCHEDULE (engine.py) against the oracle's autograd, on CPU, with the C-ABI
+contract restated in tests/emu_backend.py standing in for libsfk.  What this pins: buffer wiring, concat
+elimination, residual/shortcut gradient routing, BN statistics flow, checkpoint key scheme and layout
+conversion.  The kernels themselves are compared with the same restatement on the GPU box (test_gpu_*.py)."""
+import pytest
+import torch
+
+from emu_backend import EmuBackend, keep_mask
+from helpers import rel_err, rel_l2
+from oracle import my_slowfast as o
+from video_classification_amd import arch
+from video_classification_amd.slowfast import SlowFast
+
+
+def randomize(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            if k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+            elif ".norm" in k and k.endswith("weight"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif ".norm" in k and k.endswith("bias"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+            elif k.endswith("proj.weight"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+
+
+def make_models(ref_style, num_class=7, dtype=torch.float32, device="cpu", backend=None):
+    torch.manual_seed(1234)   # the oracle's conv init draws from the global RNG
+    if ref_style:
+        spec = arch.ref_spec(num_class=num_class, depth=18, head_pool_kernels=((2, 2, 2), (2, 2, 2)))
+        om = o.mini_slowfast(num_class, ref_style=True)
+    else:
+        spec = arch.canonical_spec(num_class=num_class, depth=18, head_pool_kernels=((2, 2, 2), (8, 2, 2)))
+        om = o.mini_slowfast(num_class, ref_style=False)
+    randomize(om, 3)
+    m = SlowFast(spec, dtype=dtype, device=device, backend=backend if backend is not None else EmuBackend())
+    m.load_state_dict(om.state_dict(), strict=True)
+    return om, m
+
+
+def make_inputs(ref_style, n=2):
+    g = torch.Generator().manual_seed(5)
+    if ref_style:
+        clips = torch.randn(n, 4, 21, 64, 64, generator=g)          # dataset memory layout N,T,C,H,W
+        return o.prepare_slowfast_data(clips)                      # strided NCTHW views, as train.py:136-140
+    frames = torch.randn(n, 3, 8, 64, 64, generator=g)
+    return o.pack_pathway(frames)
+
+
+def oracle_train_step_with_engine_mask(om, eng, x, labels):
+    """Oracle forward/backward in train mode with the ENGINE's counter-based dropout mask injected into the
+    oracle's head (replaces nn.Dropout), so both sides see the same Bernoulli draw."""
+    n = x[0].shape[0]
+    seed = int(eng.drop_seed[0]) + 1                    # Engine.forward() bumps the seed before running
+    c_s = eng.wiring.stages[3][0][-1].conv_c.geom.cout
+
+    def pre_head(mod, inp):
+        f = inp[0]                                      # (n, 2304, T', H', W')
+        P = f[0, 0].numel()
+        ks = torch.from_numpy(keep_mask(seed, n, c_s, 0, P, 0.5)).view(n, c_s, *f.shape[2:])
+        kf = torch.from_numpy(keep_mask(seed, n, f.shape[1] - c_s, c_s, P, 0.5)).view(n, -1, *f.shape[2:])
+        return (f * (torch.cat([ks, kf], 1).float() / 0.5),)
+
+    saved = om.blocks[6].dropout
+    om.blocks[6].dropout = torch.nn.Identity()
+    h = om.blocks[6].register_forward_pre_hook(pre_head)
+    om.train()
+    y = om([t for t in x])
+    loss = torch.nn.functional.cross_entropy(y, labels)
+    for p in om.parameters():
+        p.grad = None
+    loss.backward()
+    h.remove()
+    om.blocks[6].dropout = saved
+    return y.detach(), loss.detach()
+
+
+def oracle_grad_noise(om, eng, x, labels, eps=1e-7):
+    """How far the ORACLE's own parameter gradients move (relative L2, per key) when the input is perturbed by
+    ~1 fp32 ulp.  Train-mode BN + ReLU + MaxPool make the gradient discontinuous (a near-zero pre-activation or a
+    near-tie arg-max resolves differently), so this floor sits around 1e-2 for the mini model; a wiring error in
+    the engine shows up as O(1)."""
+    g0 = {k: p.grad.clone() for k, p in om.named_parameters() if p.grad is not None}
+    gen = torch.Generator().manual_seed(99)
+    xp = [t * (1 + eps * torch.randn(t.shape, generator=gen)) for t in x]
+    seed_before = eng.drop_seed.clone()
+    state_before = {k: v.clone() for k, v in om.state_dict().items()}   # BN running stats advance in train mode
+    oracle_train_step_with_engine_mask(om, eng, xp, labels)
+    om.load_state_dict(state_before)
+    eng.drop_seed.copy_(seed_before)
+    noise = {k: rel_l2(p.grad, g0[k]) for k, p in om.named_parameters() if p.grad is not None}
+    for k, p in om.named_parameters():
+        if p.grad is not None:
+            p.grad = g0[k]
+    return noise
+
+
+def grad_tolerance(noise, k, floor=3e-2, cap=0.15):  # one flip costs ~1e-2 even when the probe saw none
+    return min(cap, max(floor, 4.0 * max(noise.values()), 4.0 * noise[k]))
+
+
+def engine_grads_as_state_dict(eng):
+    """Read the gradient arena through the checkpoint layout conversion (reference tensor shapes)."""
+    keep = eng.P.data.clone()
+    eng.P.data.copy_(eng.G)
+    gsd = eng.state_dict()
+    eng.P.data.copy_(keep)
+    return gsd
+
+
+@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
+def test_state_dict_roundtrip_and_counts(ref_style):
+    om, m = make_models(ref_style)
+    sd_o, sd_m = om.state_dict(), m.state_dict()
+    assert set(sd_m) == set(sd_o)
+    for k in sd_o:
+        assert tuple(sd_o[k].shape) == tuple(sd_m[k].shape), k
+        assert torch.equal(sd_o[k].float(), sd_m[k].float().cpu()), k
+    assert m.num_parameters() == sum(p.numel() for p in om.parameters())
+
+
+def test_full_size_parameter_counts():
+    # arena bookkeeping only (no kernels run): the three pinned counts of SURVEY.md section 8c
+    from video_classification_amd.engine import Engine
+    e = Engine(arch.canonical_spec(400), dtype=torch.float32, device="cpu", backend=EmuBackend())
+    assert e.num_parameters() == 34_566_488
+    e = Engine(arch.ref_spec(249), dtype=torch.float32, device="cpu", backend=EmuBackend())
+    assert e.num_parameters() == 38_077_321 and e.num_parameters(live_only=True) == 34_052_161
+
+
+@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
+def test_eval_forward_matches_oracle(ref_style):
+    om, m = make_models(ref_style)
+    x = make_inputs(ref_style)
+    om.eval(); m.eval()
+    with torch.no_grad():
+        want = om(list(x))
+    got = m(list(x))
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
+def test_train_step_matches_oracle(ref_style):
+    om, m = make_models(ref_style)
+    x = make_inputs(ref_style)
+    m.train()
+    eng = m.engine
+    labels = torch.tensor([1, 4])
+    y_o, loss_o = oracle_train_step_with_engine_mask(om, eng, x, labels)
+    noise = oracle_grad_noise(om, eng, x, labels)
+
+    y_m = m(list(x))
+    loss_m = torch.nn.functional.cross_entropy(y_m, labels)
+    loss_m.backward()
+    assert rel_err(y_m.detach(), y_o) < 1e-4
+    assert abs(float(loss_m.detach()) - float(loss_o)) < 1e-4
+    assert m.arena.grad is not None and torch.equal(m.arena.grad, eng.G)
+
+    gsd = engine_grads_as_state_dict(eng)
+    for k, p in om.named_parameters():
+        if ".residual." in k or ".res_unit." in k:
+            assert p.grad is None                         # dead branches of the reference fusion get no gradient
+            continue
+        e = rel_l2(gsd[k].cpu(), p.grad)
+        assert e < grad_tolerance(noise, k), (k, e, noise[k])
+    # running statistics advanced exactly like nn.BatchNorm3d
+    osd = om.state_dict()
+    for L in eng.layers:
+        nk = L.cb.norm_key
+        assert rel_err(L.rm.cpu(), osd[nk + ".running_mean"]) < 1e-4, nk
+        assert rel_err(L.rv.cpu(), osd[nk + ".running_var"]) < 1e-4, nk
+        assert int(L.nbt[0]) == int(osd[nk + ".num_batches_tracked"])
+
+
+def test_load_state_dict_strictness():
+    om, m = make_models(True)
+    sd = om.state_dict()
+    sd.pop("blocks.6.proj.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd, strict=True)
+    res = m.load_state_dict(sd, strict=False)
+    assert res.missing_keys == ["blocks.6.proj.bias"]

@@ -1,0 +1,420 @@
+"""ctypes binding of include/sfk.h and the HIP backend the engine drives.
+
+There is NO fallback: if libsfk.so is missing or fails to load, ``load()`` raises.  The engine talks to a
+*backend* object whose methods mirror the C entry points and return zero-allocation closures ``run(stream)``
+with every descriptor pre-built, so a training step is a flat list of C calls on one hipStream (and can be
+captured into a hipGraph).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsfk.so")
+SFK_F32, SFK_BF16 = 0, 1
+SFK_MAX_TAPS = 16
+_DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
+
+
+class SfkError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- python-side descriptors
+@dataclass
+class FMap:
+    """Channels-last feature map view: element (n,t,h,w,c) at buf[(((n*T+t)*H+h)*W+w)*ld + c_off + c]."""
+    buf: torch.Tensor
+    n: int
+    t: int
+    h: int
+    w: int
+    c: int
+    ld: int = 0
+    c_off: int = 0
+
+    def __post_init__(self):
+        if self.ld == 0:
+            self.ld = self.c
+        assert self.ld >= self.c_off + self.c
+        assert self.buf.numel() >= self.pixels * self.ld, (self.buf.numel(), self.pixels, self.ld)
+
+    @property
+    def pixels(self) -> int:
+        return self.n * self.t * self.h * self.w
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.buf.dtype
+
+    def channels(self, c0: int, c: int) -> "FMap":
+        assert 0 <= c0 and c0 + c <= self.c
+        return FMap(self.buf, self.n, self.t, self.h, self.w, c, self.ld, self.c_off + c0)
+
+    def view5(self) -> torch.Tensor:
+        """(N,T,H,W,C) strided torch view of this map (for tests and host-side glue)."""
+        return self.buf[: self.pixels * self.ld].view(self.n, self.t, self.h, self.w, self.ld)[
+            ..., self.c_off:self.c_off + self.c]
+
+    def like(self, buf: torch.Tensor, c: Optional[int] = None) -> "FMap":
+        c = self.c if c is None else c
+        return FMap(buf, self.n, self.t, self.h, self.w, c)
+
+
+Tap = Tuple[int, int, int, int]  # (dt, dh, dw, widx)
+
+
+@dataclass
+class ConvPass:
+    x: FMap
+    y: FMap
+    rows: Tuple[int, int, int]
+    gs: Tuple[int, int, int]
+    os: Tuple[int, int, int]
+    oo: Tuple[int, int, int]
+    taps: List[Tap]
+    w: torch.Tensor          # [cout][wtaps][cin] flat, dtype of x
+    wtaps: int
+    cin: int
+    cout: int
+    accumulate: bool = False
+    stats: Optional[torch.Tensor] = None  # fp32 [mtiles][cout][2]
+
+
+@dataclass
+class WgradPass:
+    x: FMap
+    dy: FMap
+    gs: Tuple[int, int, int]
+    taps: List[Tap]
+    dw: torch.Tensor         # fp32 [cout][wtaps][cin] flat view into the gradient arena
+    wtaps: int
+    cin: int
+    cout: int
+
+
+@dataclass
+class Im2col:
+    src: torch.Tensor        # any strided view indexed (n, c, t, h, w)
+    t_index: Optional[torch.Tensor]
+    kh: int
+    kw: int
+    stride: Tuple[int, int]
+    pad: Tuple[int, int]
+    out: FMap
+
+
+# ----------------------------------------------------------------------------- ctypes mirror of sfk.h
+class _FMap(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("t", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("c", C.c_int32), ("ld", C.c_int32), ("c_off", C.c_int32)]
+
+
+class _Tap(C.Structure):
+    _fields_ = [("dt", C.c_int8), ("dh", C.c_int8), ("dw", C.c_int8), ("widx", C.c_uint8)]
+
+
+class _ConvDesc(C.Structure):
+    _fields_ = [("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
+                ("gs", C.c_int32 * 3), ("os", C.c_int32 * 3), ("oo", C.c_int32 * 3), ("ntaps", C.c_int32),
+                ("taps", _Tap * SFK_MAX_TAPS), ("w", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p)]
+
+
+class _WgradDesc(C.Structure):
+    _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
+                ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32)]
+
+
+class _Im2colDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_dtype", C.c_int32), ("sn", C.c_int64), ("sc", C.c_int64),
+                ("st", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("cin", C.c_int32), ("t_in", C.c_int32),
+                ("h_in", C.c_int32), ("w_in", C.c_int32), ("t_index", C.c_void_p), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32),
+                ("pad_w", C.c_int32), ("out", _FMap)]
+
+
+_PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_P_FMAP = C.POINTER(_FMap)
+
+# name -> argument types (return type is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "sfk_conv_igemm": [C.POINTER(_ConvDesc), _PV],
+    "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
+    "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
+    "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
+    "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PV],
+    "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
+    "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
+    "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV],
+    "sfk_bn_bwd_reduce": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _P_FMAP, _PF, _I32,
+                          C.POINTER(C.c_int32), _PV],
+    "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PV],
+    "sfk_bn_bwd_apply": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _PF, _P_FMAP, _PV],
+    "sfk_maxpool_fwd": [_P_FMAP, _P_FMAP, _PV, _I32, _I32, _I32, _PV],
+    "sfk_maxpool_bwd": [_P_FMAP, _PV, _P_FMAP, _I32, _I32, _I32, _PV],
+    "sfk_head_pool_fwd": [_P_FMAP, _I32, _I32, _I32, _F, _PV, _PF, _I32, _I32, _PV],
+    "sfk_head_pool_bwd": [_PF, _I32, _I32, _I32, _I32, _I32, _F, _PV, _P_FMAP, _PV],
+    "sfk_head_dropout_mask": [_I32, _I32, _I32, _I32, _F, _PV, _PV, _PV],
+    "sfk_fc_fwd": [_PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
+    "sfk_fc_bwd": [_PF, _PF, _PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
+    "sfk_softmax_ce": [_PF, _PV, _I32, _I32, _F, _PF, _PF, _PF, _PV, _PV],
+    "sfk_adam": [_PF, _PF, _PF, _PF, _I64, _F, _F, _F, _F, _F, _PV, _PV, _I32, _PV],
+    "sfk_filter_transpose": [_PV, _I32, _PV, _I32, _I32, _I32, _I32, _PV],
+    "sfk_cast": [_PV, _I32, _PV, _I32, _I64, _PV],
+    "sfk_fill_zero": [_PV, C.c_size_t, _PV],
+    "sfk_abi_version": [],
+    "sfk_status_string": [C.c_int],
+}
+_RESTYPE = {"sfk_status_string": C.c_char_p}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen libsfk.so and type every entry point of include/sfk.h.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SfkError(f"{path} not found: build it with `python video-classification_amd/build.py` "
+                       "(there is no CPU or PyTorch fallback for the SlowFast path)")
+    lib = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    if lib.sfk_abi_version() != 1:
+        raise SfkError("libsfk ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(st: int, what: str):
+    if st != 0:
+        msg = load().sfk_status_string(st).decode()
+        raise SfkError(f"{what}: {msg} ({st})")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _c_fmap(f: FMap) -> _FMap:
+    return _FMap(f.buf.data_ptr(), _DT[f.buf.dtype], f.n, f.t, f.h, f.w, f.c, f.ld, f.c_off)
+
+
+def _c_taps(taps: Sequence[Tap]):
+    arr = (_Tap * SFK_MAX_TAPS)()
+    assert 0 < len(taps) <= SFK_MAX_TAPS
+    for i, (dt, dh, dw, wi) in enumerate(taps):
+        arr[i] = _Tap(dt, dh, dw, wi)
+    return arr
+
+
+def _c_conv(p: ConvPass) -> _ConvDesc:
+    d = _ConvDesc()
+    d.x, d.y = _c_fmap(p.x), _c_fmap(p.y)
+    d.rt, d.rh, d.rw = p.rows
+    d.gs = (C.c_int32 * 3)(*p.gs)
+    d.os = (C.c_int32 * 3)(*p.os)
+    d.oo = (C.c_int32 * 3)(*p.oo)
+    d.ntaps = len(p.taps)
+    d.taps = _c_taps(p.taps)
+    d.w = p.w.data_ptr()
+    d.wtaps, d.cin, d.cout = p.wtaps, p.cin, p.cout
+    d.accumulate = 1 if p.accumulate else 0
+    d.stats = _ptr(p.stats)
+    return d
+
+
+class HipBackend:
+    """Every method returns ``run(stream)``; descriptors are built once, here.  Tensors referenced by a closure
+    are kept alive by it."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load()
+
+    # -- convolution
+    def conv_igemm_mtiles(self, p: ConvPass) -> int:
+        d = _c_conv(p)
+        r = self.lib.sfk_conv_igemm_mtiles(C.byref(d))
+        if r < 0:
+            _check(r, "sfk_conv_igemm_mtiles")
+        return r
+
+    def conv_igemm(self, p: ConvPass):
+        d, fn, keep = _c_conv(p), self.lib.sfk_conv_igemm, p
+
+        def run(stream, _d=C.byref(d), _keep=(d, keep)):
+            st = fn(_d, stream)
+            if st:
+                _check(st, "sfk_conv_igemm")
+        return run
+
+    def conv_wgrad(self, p: WgradPass):
+        d = _WgradDesc()
+        d.x, d.dy = _c_fmap(p.x), _c_fmap(p.dy)
+        d.gs = (C.c_int32 * 3)(*p.gs)
+        d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)
+        d.dw, d.wtaps, d.cin, d.cout = p.dw.data_ptr(), p.wtaps, p.cin, p.cout
+        fn = self.lib.sfk_conv_wgrad
+
+        def run(stream, _d=C.byref(d), _keep=(d, p)):
+            st = fn(_d, stream)
+            if st:
+                _check(st, "sfk_conv_wgrad")
+        return run
+
+    def stem_im2col(self, p: Im2col):
+        s = p.src
+        assert s.dim() == 5
+        d = _Im2colDesc()
+        d.src, d.src_dtype = s.data_ptr(), _DT[s.dtype]
+        d.sn, d.sc, d.st, d.sh, d.sw = s.stride()
+        d.cin, d.t_in, d.h_in, d.w_in = s.shape[1], s.shape[2], s.shape[3], s.shape[4]
+        d.t_index = _ptr(p.t_index)
+        d.kh, d.kw = p.kh, p.kw
+        d.stride_h, d.stride_w = p.stride
+        d.pad_h, d.pad_w = p.pad
+        d.out = _c_fmap(p.out)
+        fn = self.lib.sfk_stem_im2col
+
+        def run(stream, _d=C.byref(d), _keep=(d, p)):
+            st = fn(_d, stream)
+            if st:
+                _check(st, "sfk_stem_im2col")
+        return run
+
+    # -- generic plain-argument entry points
+    def _plain(self, name, *args, keep=()):
+        fn = getattr(self.lib, name)
+        cargs = tuple(args)
+
+        def run(stream, _a=cargs, _keep=keep):
+            st = fn(*_a, stream)
+            if st:
+                _check(st, name)
+        return run
+
+    def bn_finalize(self, partials, nparts, c, count, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                    mean, invstd, scale, shift):
+        ts = (partials, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift)
+        return self._plain("sfk_bn_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
+                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd), _ptr(scale),
+                           _ptr(shift), keep=ts)
+
+    def bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift):
+        return self._plain("sfk_bn_eval_coeffs", _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), eps, c, _ptr(scale),
+                           _ptr(shift), keep=(gamma, beta, rm, rv, scale, shift))
+
+    def bn_stats(self, y: FMap, partials, max_parts):
+        """returns (run, nparts)"""
+        fy = _c_fmap(y)
+        np_ = C.c_int32(0)
+        run = self._plain("sfk_bn_stats", C.byref(fy), _ptr(partials), max_parts, C.byref(np_),
+                          keep=(fy, np_, y, partials))
+        return run, self._dry_parts(y, max_parts)
+
+    @staticmethod
+    def _dry_parts(y: FMap, max_parts: int) -> int:
+        # mirrors chan_grid() in csrc/bn.hip
+        vec = 8 if y.dtype == torch.bfloat16 else 4
+        cgs = y.c // vec
+        cgs_b = min(cgs, 256)
+        rows_b = 256 // cgs_b
+        parts = (y.pixels + rows_b * 16 - 1) // (rows_b * 16)
+        cchunks = (cgs + 255) // 256
+        parts = min(parts, max(1, 2048 // cchunks))
+        if max_parts > 0:
+            parts = min(parts, max_parts)
+        return max(1, parts)
+
+    def bn_apply(self, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap):
+        fy, fo = _c_fmap(y), _c_fmap(out)
+        fr = _c_fmap(res) if res is not None else None
+        return self._plain("sfk_bn_apply", C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fr) if fr else None,
+                           _ptr(res_scale), _ptr(res_shift), 1 if relu else 0, C.byref(fo),
+                           keep=(fy, fo, fr, y, out, res, scale, shift, res_scale, res_shift))
+
+    def bn_bwd_reduce(self, da: FMap, y: FMap, mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool,
+                      dz_out: Optional[FMap], partials, max_parts):
+        """returns (run, nparts)"""
+        fa, fy = _c_fmap(da), _c_fmap(y)
+        fm = _c_fmap(mask_src) if mask_src is not None else None
+        fz = _c_fmap(dz_out) if dz_out is not None else None
+        np_ = C.c_int32(0)
+        run = self._plain("sfk_bn_bwd_reduce", C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean),
+                          _ptr(invstd), _ptr(scale), _ptr(shift), 1 if relu else 0, C.byref(fz) if fz else None,
+                          _ptr(partials), max_parts, C.byref(np_),
+                          keep=(fa, fy, fm, fz, np_, da, y, mask_src, dz_out, mean, invstd, scale, shift, partials))
+        return run, self._dry_parts(y, max_parts)
+
+    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef):
+        return self._plain("sfk_bn_bwd_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(invstd),
+                           _ptr(dgamma), _ptr(dbeta), _ptr(coef), keep=(partials, gamma, invstd, dgamma, dbeta, coef))
+
+    def bn_bwd_apply(self, da: FMap, y: FMap, mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool, coef,
+                     dy: FMap):
+        fa, fy, fo = _c_fmap(da), _c_fmap(y), _c_fmap(dy)
+        fm = _c_fmap(mask_src) if mask_src is not None else None
+        return self._plain("sfk_bn_bwd_apply", C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean),
+                           _ptr(invstd), _ptr(scale), _ptr(shift), 1 if relu else 0, _ptr(coef), C.byref(fo),
+                           keep=(fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift, coef))
+
+    # -- pooling / head / loss
+    def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):
+        fx, fy = _c_fmap(x), _c_fmap(y)
+        return self._plain("sfk_maxpool_fwd", C.byref(fx), C.byref(fy), _ptr(argmax), k, s, p, keep=(fx, fy, x, y, argmax))
+
+    def maxpool_bwd(self, dy: FMap, argmax, dx: FMap, k, s, p):
+        fy, fx = _c_fmap(dy), _c_fmap(dx)
+        return self._plain("sfk_maxpool_bwd", C.byref(fy), _ptr(argmax), C.byref(fx), k, s, p, keep=(fx, fy, dx, dy, argmax))
+
+    def head_pool_fwd(self, x: FMap, k, rate, seed, feat, feat_ld, f_off):
+        fx = _c_fmap(x)
+        return self._plain("sfk_head_pool_fwd", C.byref(fx), k[0], k[1], k[2], rate, _ptr(seed), _ptr(feat), feat_ld,
+                           f_off, keep=(fx, x, seed, feat))
+
+    def head_pool_bwd(self, dfeat, feat_ld, f_off, k, rate, seed, dx: FMap):
+        fx = _c_fmap(dx)
+        return self._plain("sfk_head_pool_bwd", _ptr(dfeat), feat_ld, f_off, k[0], k[1], k[2], rate, _ptr(seed),
+                           C.byref(fx), keep=(fx, dx, seed, dfeat))
+
+    def head_dropout_mask(self, n, c, f_off, positions, rate, seed, mask):
+        return self._plain("sfk_head_dropout_mask", n, c, f_off, positions, rate, _ptr(seed), _ptr(mask), keep=(seed, mask))
+
+    def fc_fwd(self, feat, w, b, logits, n, f, k):
+        return self._plain("sfk_fc_fwd", _ptr(feat), _ptr(w), _ptr(b), _ptr(logits), n, f, k, keep=(feat, w, b, logits))
+
+    def fc_bwd(self, dlogits, feat, w, dfeat, dw, db, n, f, k):
+        return self._plain("sfk_fc_bwd", _ptr(dlogits), _ptr(feat), _ptr(w), _ptr(dfeat), _ptr(dw), _ptr(db), n, f, k,
+                           keep=(dlogits, feat, w, dfeat, dw, db))
+
+    def softmax_ce(self, logits, labels, n, k, gscale, dlogits, loss_out, loss_sum, correct):
+        return self._plain("sfk_softmax_ce", _ptr(logits), _ptr(labels), n, k, gscale, _ptr(dlogits), _ptr(loss_out),
+                           _ptr(loss_sum), _ptr(correct), keep=(logits, labels, dlogits, loss_out, loss_sum, correct))
+
+    # -- optimiser / misc
+    def adam(self, p, g, m, v, count, lr, b1, b2, eps, gscale, step, shadow=None):
+        sd = _DT[shadow.dtype] if shadow is not None else SFK_F32
+        return self._plain("sfk_adam", _ptr(p), _ptr(g), _ptr(m), _ptr(v), count, lr, b1, b2, eps, gscale, _ptr(step),
+                           _ptr(shadow), sd, keep=(p, g, m, v, step, shadow))
+
+    def filter_transpose(self, src, dst, cout, wtaps, cin):
+        return self._plain("sfk_filter_transpose", _ptr(src), _DT[src.dtype], _ptr(dst), _DT[dst.dtype], cout, wtaps,
+                           cin, keep=(src, dst))
+
+    def cast(self, src, dst, count):
+        return self._plain("sfk_cast", _ptr(src), _DT[src.dtype], _ptr(dst), _DT[dst.dtype], count, keep=(src, dst))
+
+    def fill_zero(self, t: torch.Tensor):
+        return self._plain("sfk_fill_zero", t.data_ptr(), t.numel() * t.element_size(), keep=(t,))

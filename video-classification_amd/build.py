@@ -1,0 +1,46 @@
+"""Build libsfk.so (the C-ABI kernel library of include/sfk.h) with hipcc for gfx950, in-tree."""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsfk.so")
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "bn.hip", "pool_head.hip", "optim_misc.hip"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(CSRC, "sfk_common.h"), os.path.join(ROOT, "include", "sfk.h")]
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            return o, True
+        return o, False
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        res = list(ex.map(compile_one, SOURCES))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or not os.path.exists(LIB):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in os.sys.argv, verbose=True))

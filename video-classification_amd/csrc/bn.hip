@@ -1,0 +1,461 @@
+// BatchNorm3d (+ReLU, +residual add) forward / backward on channels-last feature maps.
+// All of these are HBM-bound streaming kernels: 16 B per lane, a thread owns ONE group of VEC channels for its
+// whole lifetime (per-channel coefficients live in registers) and walks pixels; per-channel reductions end
+// in a per-block partial row that a tiny finalize kernel folds in double precision (deterministic, no atomics).
+#include "sfk_common.h"
+
+namespace {
+
+struct FM {  // kernel-side feature map view
+  void* p;
+  int ld, off;
+};
+inline FM fm_of(const sfk_fmap* f) { return FM{f ? f->ptr : nullptr, f ? f->ld : 0, f ? f->c_off : 0}; }
+
+// thread -> (channel group, first pixel, pixel step) ; blockDim = 256, grid = (pixel parts, channel-group chunks)
+struct ChanMap {
+  int cg, row, rows_b;
+  bool active;
+  __device__ __forceinline__ ChanMap(int cgs) {
+    const int cgs_b = cgs < 256 ? cgs : 256;
+    rows_b = 256 / cgs_b;
+    const int tx = threadIdx.x % cgs_b, ty = threadIdx.x / cgs_b;
+    cg = blockIdx.y * 256 + tx;
+    row = ty;
+    active = ty < rows_b && cg < cgs;
+  }
+};
+
+inline dim3 chan_grid(int cgs, int64_t pixels, int max_parts, int* nparts) {
+  const int cgs_b = cgs < 256 ? cgs : 256;
+  const int rows_b = 256 / cgs_b;
+  int64_t parts = (pixels + (int64_t)rows_b * 16 - 1) / ((int64_t)rows_b * 16);  // >= 16 pixels per thread
+  const int cchunks = (cgs + 255) / 256;
+  int64_t cap = 2048 / cchunks;
+  if (cap < 1) cap = 1;
+  if (parts > cap) parts = cap;
+  if (max_parts > 0 && parts > max_parts) parts = max_parts;
+  if (parts < 1) parts = 1;
+  *nparts = (int)parts;
+  return dim3((unsigned)parts, (unsigned)cchunks);
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_coef(float (&dst)[VEC], const float* src, int cg) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) dst[i] = src[cg * VEC + i];
+}
+
+// block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group
+template <int VEC>
+__device__ __forceinline__ void block_reduce_store(const ChanMap& cm, int cgs, const float (&a)[VEC],
+                                                   const float (&b)[VEC], float* partials, int c) {
+  __shared__ float red[256 * 2 * VEC];
+  float* mine = red + threadIdx.x * 2 * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mine[2 * i] = cm.active ? a[i] : 0.f;
+    mine[2 * i + 1] = cm.active ? b[i] : 0.f;
+  }
+  __syncthreads();
+  const int cgs_b = cgs < 256 ? cgs : 256;
+  const int ty = threadIdx.x / cgs_b;
+  if (ty == 0 && cm.cg < cgs) {
+    float sa[VEC], sb[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+    for (int r = 0; r < cm.rows_b; ++r) {
+      const float* o = red + (r * cgs_b + threadIdx.x) * 2 * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { sa[i] += o[2 * i]; sb[i] += o[2 * i + 1]; }
+    }
+    float* out = partials + ((int64_t)blockIdx.x * c + cm.cg * VEC) * 2;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { out[2 * i] = sa[i]; out[2 * i + 1] = sb[i]; }
+  }
+}
+
+// ------------------------------------------------------------------ forward statistics (stand-alone)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(FM y, int64_t pixels, int c, float* partials) {
+  constexpr int VEC = DT<T>::VEC;
+  const int cgs = c / VEC;
+  const ChanMap cm(cgs);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (cm.active) {
+    const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+    for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
+      Vec16<T> v;
+      v.load(yp + p * y.ld);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float f = v.get(i);
+        s1[i] += f;
+        s2[i] += f * f;
+      }
+    }
+  }
+  block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
+}
+
+// one wave per channel: lanes stride over the partial rows, butterfly in double
+__device__ __forceinline__ void wave_sum_partials(const float* partials, int nparts, int c, int ch, double& s1,
+                                                  double& s2) {
+  const int lane = threadIdx.x & 63;
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int p = lane; p < nparts; p += 64) {
+    const float2 v = *reinterpret_cast<const float2*>(partials + ((int64_t)p * c + ch) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) {
+    s1 += __shfl_xor(s1, sft);
+    s2 += __shfl_xor(s2, sft);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int nparts, int c, double count,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          int64_t* nbt, float* mean, float* invstd, float* scale,
+                                                          float* shift) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  if (ch >= c) return;
+  double s1, s2;
+  wave_sum_partials(partials, nparts, c, ch, s1, s2);
+  if ((threadIdx.x & 63) != 0) return;
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * is;
+  mean[ch] = (float)mu;
+  invstd[ch] = is;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - (float)mu * sc;
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int c, float* scale, float* shift) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float is = 1.f / sqrtf(rv[ch] + eps);
+  const float sc = gamma[ch] * is;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - rm[ch] * sc;
+}
+
+// ------------------------------------------------------------------ forward apply
+// RES: 0 none, 1 plain residual, 2 residual with its own scale/shift (projection shortcut's BN)
+template <typename T, int RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
+                                                       const float* scale, const float* shift,
+                                                       const float* rscale, const float* rshift) {
+  constexpr int VEC = DT<T>::VEC;
+  const int cgs = c / VEC;
+  const ChanMap cm(cgs);
+  if (!cm.active) return;
+  float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
+  load_coef<VEC>(sc, scale, cm.cg);
+  load_coef<VEC>(sh, shift, cm.cg);
+  if (RES == 2) {
+    load_coef<VEC>(rsc, rscale, cm.cg);
+    load_coef<VEC>(rsh, rshift, cm.cg);
+  }
+  const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+  const T* rp = RES ? static_cast<const T*>(res.p) + res.off + cm.cg * VEC : nullptr;
+  T* op = static_cast<T*>(out.p) + out.off + cm.cg * VEC;
+  for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
+    Vec16<T> v, r, o;
+    v.load(yp + p * y.ld);
+    if (RES) r.load(rp + p * res.ld);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float f = v.get(i) * sc[i] + sh[i];
+      if (RES == 1) f += r.get(i);
+      if (RES == 2) f += r.get(i) * rsc[i] + rsh[i];
+      if (RELU) f = f > 0.f ? f : 0.f;
+      o.set(i, f);
+    }
+    o.store(op + p * out.ld);
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0)
+template <typename T, int MASK, bool WRITE_DZ>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc, FM dzo, int64_t pixels, int c,
+                                                            const float* mean, const float* invstd,
+                                                            const float* scale, const float* shift,
+                                                            float* partials) {
+  constexpr int VEC = DT<T>::VEC;
+  const int cgs = c / VEC;
+  const ChanMap cm(cgs);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (cm.active) {
+    float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+    load_coef<VEC>(mu, mean, cm.cg);
+    load_coef<VEC>(is, invstd, cm.cg);
+    if (MASK == 1) {
+      load_coef<VEC>(sc, scale, cm.cg);
+      load_coef<VEC>(sh, shift, cm.cg);
+    }
+    const T* dap = static_cast<const T*>(da.p) + da.off + cm.cg * VEC;
+    const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+    const T* mp = MASK == 2 ? static_cast<const T*>(msrc.p) + msrc.off + cm.cg * VEC : nullptr;
+    T* zp = WRITE_DZ ? static_cast<T*>(dzo.p) + dzo.off + cm.cg * VEC : nullptr;
+    for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
+      Vec16<T> d, v, m, z;
+      d.load(dap + p * da.ld);
+      v.load(yp + p * y.ld);
+      if (MASK == 2) m.load(mp + p * msrc.ld);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float yv = v.get(i);
+        float dz = d.get(i);
+        if (MASK == 1) dz = (yv * sc[i] + sh[i] > 0.f) ? dz : 0.f;
+        if (MASK == 2) dz = (m.get(i) > 0.f) ? dz : 0.f;
+        if (WRITE_DZ) z.set(i, dz);
+        s1[i] += dz;
+        s2[i] += dz * ((yv - mu[i]) * is[i]);
+      }
+      if (WRITE_DZ) z.store(zp + p * dzo.ld);
+    }
+  }
+  block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, int c,
+                                                              double count, const float* gamma,
+                                                              const float* invstd, float* dgamma, float* dbeta,
+                                                              float* coef) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;
+  double s1, s2;
+  wave_sum_partials(partials, nparts, c, ch, s1, s2);
+  if ((threadIdx.x & 63) != 0) return;
+  if (dgamma) dgamma[ch] += (float)s2;
+  if (dbeta) dbeta[ch] += (float)s1;
+  coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
+  coef[ch * 3 + 1] = (float)(s1 / count);
+  coef[ch * 3 + 2] = (float)(s2 / count);
+}
+
+template <typename T, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
+                                                           const float* mean, const float* invstd,
+                                                           const float* scale, const float* shift,
+                                                           const float* coef) {
+  constexpr int VEC = DT<T>::VEC;
+  const int cgs = c / VEC;
+  const ChanMap cm(cgs);
+  if (!cm.active) return;
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], c0[VEC], c1[VEC], c2[VEC];
+  load_coef<VEC>(mu, mean, cm.cg);
+  load_coef<VEC>(is, invstd, cm.cg);
+  if (MASK == 1) {
+    load_coef<VEC>(sc, scale, cm.cg);
+    load_coef<VEC>(sh, shift, cm.cg);
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    c0[i] = coef[(cm.cg * VEC + i) * 3 + 0];
+    c1[i] = coef[(cm.cg * VEC + i) * 3 + 1];
+    c2[i] = coef[(cm.cg * VEC + i) * 3 + 2];
+  }
+  const T* dap = static_cast<const T*>(da.p) + da.off + cm.cg * VEC;
+  const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+  const T* mp = MASK == 2 ? static_cast<const T*>(msrc.p) + msrc.off + cm.cg * VEC : nullptr;
+  T* op = static_cast<T*>(dyo.p) + dyo.off + cm.cg * VEC;
+  for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
+    Vec16<T> d, v, m, o;
+    d.load(dap + p * da.ld);
+    v.load(yp + p * y.ld);
+    if (MASK == 2) m.load(mp + p * msrc.ld);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float yv = v.get(i);
+      float dz = d.get(i);
+      if (MASK == 1) dz = (yv * sc[i] + sh[i] > 0.f) ? dz : 0.f;
+      if (MASK == 2) dz = (m.get(i) > 0.f) ? dz : 0.f;
+      o.set(i, c0[i] * (dz - c1[i] - (yv - mu[i]) * is[i] * c2[i]));
+    }
+    o.store(op + p * dyo.ld);
+  }
+}
+
+bool same_shape(const sfk_fmap* a, const sfk_fmap* b) {
+  return a->n == b->n && a->t == b->t && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
+}
+
+}  // namespace
+
+extern "C" int sfk_bn_stats(const sfk_fmap* y, float* partials, int32_t max_parts, int32_t* nparts_out,
+                            sfk_stream_t stream) {
+  if (!sfk_fmap_ok(y) || !partials || !nparts_out || max_parts <= 0) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(y)) return SFK_ERR_UNSUPPORTED;
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  const dim3 grid = chan_grid(y->c / sfk_vec_of(y->dtype), px, max_parts, &np);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (y->dtype == SFK_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, fm_of(y), px, y->c, partials);
+  else hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, fm_of(y), px, y->c, partials);
+  SFK_CHECK_LAUNCH();
+  *nparts_out = np;
+  return SFK_OK;
+}
+
+extern "C" int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                               float* scale, float* shift, sfk_stream_t stream) {
+  if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift)
+    return SFK_ERR_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SFK_ERR_INVALID;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+                     nparts, c, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
+                     num_batches_tracked, mean, invstd, scale, shift);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int32_t c, float* scale, float* shift,
+                                  sfk_stream_t stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || c <= 0) return SFK_ERR_INVALID;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((c + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), gamma,
+                     beta, running_mean, running_var, eps, c, scale, shift);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+namespace {
+template <typename T>
+int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
+                 const float* rs, const float* rb, int relu, const sfk_fmap* out, hipStream_t s) {
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np), blk(256);
+  const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
+  const int mode = !res ? 0 : (rs ? 2 : 1);
+#define SFK_APPLY(R, A) hipLaunchKernelGGL((bn_apply_kernel<T, R, A>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb)
+  if (relu) {
+    if (mode == 0) SFK_APPLY(0, true); else if (mode == 1) SFK_APPLY(1, true); else SFK_APPLY(2, true);
+  } else {
+    if (mode == 0) SFK_APPLY(0, false); else if (mode == 1) SFK_APPLY(1, false); else SFK_APPLY(2, false);
+  }
+#undef SFK_APPLY
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+}  // namespace
+
+extern "C" int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
+                            const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
+                            sfk_stream_t stream) {
+  if (!sfk_fmap_ok(y) || !sfk_fmap_ok(out) || !scale || !shift || !same_shape(y, out)) return SFK_ERR_INVALID;
+  if (res && (!sfk_fmap_ok(res) || !same_shape(y, res))) return SFK_ERR_INVALID;
+  if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res))) return SFK_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return y->dtype == SFK_BF16 ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, s)
+                              : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, s);
+}
+
+namespace {
+int check_bwd(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
+              const float* invstd, const float* scale, const float* shift, int relu) {
+  if (!sfk_fmap_ok(da) || !sfk_fmap_ok(y) || !same_shape(da, y) || !mean || !invstd) return SFK_ERR_INVALID;
+  if (mask_src && (!sfk_fmap_ok(mask_src) || !same_shape(da, mask_src))) return SFK_ERR_INVALID;
+  if (!mask_src && relu && (!scale || !shift)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(da) || !sfk_fmap_vec_ok(y) || (mask_src && !sfk_fmap_vec_ok(mask_src))) return SFK_ERR_UNSUPPORTED;
+  return SFK_OK;
+}
+
+template <typename T>
+int launch_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, int relu,
+                      const sfk_fmap* dzo, float* partials, int max_parts, int* nparts_out, hipStream_t s) {
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, max_parts, &np), blk(256);
+  const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), z = fm_of(dzo);
+  const int mask = ms ? 2 : (relu ? 1 : 0);
+#define SFK_RED(M, W) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials)
+  if (dzo) {
+    if (mask == 0) SFK_RED(0, true); else if (mask == 1) SFK_RED(1, true); else SFK_RED(2, true);
+  } else {
+    if (mask == 0) SFK_RED(0, false); else if (mask == 1) SFK_RED(1, false); else SFK_RED(2, false);
+  }
+#undef SFK_RED
+  SFK_CHECK_LAUNCH();
+  *nparts_out = np;
+  return SFK_OK;
+}
+
+template <typename T>
+int launch_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, const float* mean,
+                     const float* invstd, const float* scale, const float* shift, int relu, const float* coef,
+                     const sfk_fmap* dy, hipStream_t s) {
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np), blk(256);
+  const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), o = fm_of(dy);
+  const int mask = ms ? 2 : (relu ? 1 : 0);
+#define SFK_APP(M) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, invstd, scale, shift, coef)
+  if (mask == 0) SFK_APP(0); else if (mask == 1) SFK_APP(1); else SFK_APP(2);
+#undef SFK_APP
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+}  // namespace
+
+extern "C" int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, int32_t relu,
+                                 const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
+                                 sfk_stream_t stream) {
+  const int st = check_bwd(da, y, mask_src, mean, invstd, scale, shift, relu);
+  if (st != SFK_OK) return st;
+  if (!partials || max_parts <= 0 || !nparts_out) return SFK_ERR_INVALID;
+  if (dz_out && (!sfk_fmap_ok(dz_out) || !same_shape(da, dz_out))) return SFK_ERR_INVALID;
+  if (dz_out && !sfk_fmap_vec_ok(dz_out)) return SFK_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return y->dtype == SFK_BF16
+             ? launch_bwd_reduce<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, s)
+             : launch_bwd_reduce<float>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, s);
+}
+
+extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
+                                   const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                   sfk_stream_t stream) {
+  if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !invstd || !coef) return SFK_ERR_INVALID;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partials, nparts, c, (double)count, gamma, invstd, dgamma, dbeta, coef);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, int32_t relu,
+                                const float* coef, const sfk_fmap* dy, sfk_stream_t stream) {
+  const int st = check_bwd(da, y, mask_src, mean, invstd, scale, shift, relu);
+  if (st != SFK_OK) return st;
+  if (!coef || !sfk_fmap_ok(dy) || !same_shape(da, dy)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(dy)) return SFK_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return y->dtype == SFK_BF16
+             ? launch_bwd_apply<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s)
+             : launch_bwd_apply<float>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s);
+}

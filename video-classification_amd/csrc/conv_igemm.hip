@@ -1,0 +1,334 @@
+// sfk_conv_igemm: Conv3d forward / data-gradient as an implicit GEMM on gfx950 MFMA.
+//
+//   D[co][pixel] = sum_{tap, ci} W[co][tap][ci] * X[gather(pixel, tap)][ci]
+//
+// MFMA orientation: A = filter tile (rows = co), B = gathered pixel tile (cols = pixel), so a lane ends up
+// holding 4 CONSECUTIVE output channels of one pixel -> 8-byte channels-last stores, and the per-channel
+// BatchNorm partial sums are a 16-lane butterfly.
+// Both operands are K(=ci)-contiguous in HBM (channels-last activations, [co][tap][ci] filters), so tiles are
+// staged HBM -> registers (16 B / lane, zero-filled for padding pixels and ragged channels) -> LDS, double
+// buffered: the loads of K-step i+1 are in flight while step i runs on the matrix cores.
+//   bf16: v_mfma_f32_16x16x32_bf16, LDS rows of 64 B XOR-swizzled so ds_read_b128 is conflict-free
+//   f32 : v_mfma_f32_16x16x4_f32 x8 per K-step (bit-exact fp32 fma chain) -- the parity precision
+#include "sfk_common.h"
+
+namespace {
+
+struct ConvK {
+  const void* x;
+  void* y;
+  const void* w;
+  float* stats;
+  int xt, xh, xw, xld, xoff;
+  int yt, yh, yw, yld, yoff;
+  int M;
+  FastDiv drw, drh, drt;
+  int gst, gsh, gsw, ost, osh, osw, oot, ooh, oow;
+  int cin, cout, wtaps, ntaps, KC, accumulate;
+  int mtiles, ntiles;
+  sfk_tap taps[SFK_MAX_TAPS];
+};
+
+constexpr int BK = 32;
+
+template <typename T> struct Tile;
+template <> struct Tile<bf16_t> {
+  static constexpr int VEC = 8, SEGS = 4, ROWB = 64;
+  // 16-byte slot s of row r; the XOR makes the four 16-lane groups of ds_read_b128 hit 16 distinct slots
+  static __device__ __forceinline__ int off(int r, int s) { return r * ROWB + ((s ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); }
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag load(const char* tile, int r, int g) {
+    return *reinterpret_cast<const frag*>(tile + off(r, g));
+  }
+  static __device__ __forceinline__ void mma(f32x4& acc, const frag& a, const frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct Tile<float> {
+  static constexpr int VEC = 4, SEGS = 8, ROWB = 144;  // 128 B of data + 16 B pad
+  static __device__ __forceinline__ int off(int r, int s) { return r * ROWB + (s << 4); }
+  struct frag { float4 lo, hi; };
+  static __device__ __forceinline__ frag load(const char* tile, int r, int g) {
+    frag f;
+    f.lo = *reinterpret_cast<const float4*>(tile + off(r, 2 * g));
+    f.hi = *reinterpret_cast<const float4*>(tile + off(r, 2 * g + 1));
+    return f;
+  }
+  // lane group g holds k = 8g..8g+7; MFMA step s consumes element s of every group (A and B agree on k)
+  static __device__ __forceinline__ void mma(f32x4& acc, const frag& a, const frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void store4(float* p, const f32x4& v, bool acc) {
+  float4 o = make_float4(v[0], v[1], v[2], v[3]);
+  if (acc) {
+    const float4 old = *reinterpret_cast<const float4*>(p);
+    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+  }
+  *reinterpret_cast<float4*>(p) = o;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, bool acc) {
+  float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+  if (acc) {
+    const bf16x4 old = *reinterpret_cast<const bf16x4*>(p);
+    a0 += (float)old[0]; a1 += (float)old[1]; a2 += (float)old[2]; a3 += (float)old[3];
+  }
+  bf16x4 o;
+  o[0] = (bf16_t)a0; o[1] = (bf16_t)a1; o[2] = (bf16_t)a2; o[3] = (bf16_t)a3;
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
+  using TL = Tile<T>;
+  constexpr int VEC = TL::VEC, SEGS = TL::SEGS, ROWB = TL::ROWB;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  constexpr int RPI = 256 / SEGS;              // tile rows covered by one pass of the 256 threads
+  constexpr int XL = BM / RPI;                 // gathered-pixel loads per thread per K-step
+  constexpr int WL = (BN + RPI - 1) / RPI;     // filter loads per thread per K-step
+  constexpr int BUF = (BM + BN) * ROWB;
+  static_assert(WM * WN == 4 && BM % RPI == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an L2; give them the SAME pixel tile (all its co tiles)
+  int mt, nt;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    nt = logical % k.ntiles;
+    mt = logical / k.ntiles;
+  }
+
+  // ---- per-thread staging coordinates (fixed over the K loop)
+  const int seg = tid % SEGS, row0 = tid / SEGS;
+  int xn[XL], xtb[XL], xhb[XL], xwb[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int m = mt * BM + row0 + i * RPI;
+    uint32_t q1, rw_, q2, rh_, n_, rt_;
+    k.drw.divmod((uint32_t)m, q1, rw_);
+    k.drh.divmod(q1, q2, rh_);
+    k.drt.divmod(q2, n_, rt_);
+    xn[i] = (int)n_;
+    xtb[i] = (m < k.M) ? (int)rt_ * k.gst : -(1 << 28);  // rows past M gather nothing
+    xhb[i] = (int)rh_ * k.gsh;
+    xwb[i] = (int)rw_ * k.gsw;
+  }
+  const T* __restrict__ xp = static_cast<const T*>(k.x);
+  const T* __restrict__ wp = static_cast<const T*>(k.w);
+
+  uint4 xr[XL], wr[WL];
+  auto gload = [&](int tap, int kc) {
+    const sfk_tap tp = k.taps[tap];
+    const int c = kc * BK + seg * VEC;
+    const bool cok = c < k.cin;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int ti = xtb[i] + tp.dt, hi = xhb[i] + tp.dh, wi = xwb[i] + tp.dw;
+      const bool ok = cok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
+                      (unsigned)wi < (unsigned)k.xw;
+      const int64_t off = ((((int64_t)xn[i] * k.xt + ti) * k.xh + hi) * k.xw + wi) * k.xld + k.xoff + c;
+      xr[i] = ok ? *reinterpret_cast<const uint4*>(xp + off) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int r = row0 + i * RPI;
+      const int co = nt * BN + r;
+      const bool ok = cok && r < BN && co < k.cout;
+      const int64_t off = ((int64_t)co * k.wtaps + tp.widx) * k.cin + c;
+      wr[i] = ok ? *reinterpret_cast<const uint4*>(wp + off) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* xs = smem + buf * BUF;
+    char* ws = xs + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) *reinterpret_cast<uint4*>(xs + TL::off(row0 + i * RPI, seg)) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int r = row0 + i * RPI;
+      if (r < BN) *reinterpret_cast<uint4*>(ws + TL::off(r, seg)) = wr[i];
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nit = k.ntaps * k.KC;
+  int tap = 0, kc = 0;
+  gload(0, 0);
+  lstore(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (++kc == k.KC) { kc = 0; ++tap; }
+    const bool more = it + 1 < nit;
+    if (more) gload(tap, kc);
+    const char* xs = smem + buf * BUF;
+    const char* ws = xs + BM * ROWB;
+    typename TL::frag a[FN], b[FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) a[i] = TL::load(ws, wn * (BN / WN) + 16 * i + l15, g);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) b[j] = TL::load(xs, wm * (BM / WM) + 16 * j + l15, g);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) TL::mma(acc[i][j], a[i], b[j]);
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
+  T* __restrict__ yp = static_cast<T*>(k.y);
+  const int co_w = nt * BN + wn * (BN / WN);
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (m < k.M) {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int co = co_w + 16 * i + 4 * g;
+        if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+      }
+    }
+  }
+
+  // ---- BatchNorm partial statistics of this tile (rows past M accumulated zeros, so they add nothing)
+  if (k.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; all LDS reads of the K loop are behind a barrier
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) {
+          s1 += __shfl_xor(s1, sft);
+          s2 += __shfl_xor(s2, sft);
+        }
+        if (l15 == 0) {
+          const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < k.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) {
+          s1 += red[(w_ * BN + tid) * 2 + 0];
+          s2 += red[(w_ * BN + tid) * 2 + 1];
+        }
+        float* o = k.stats + ((int64_t)mt * k.cout + co) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+    }
+  }
+}
+
+struct TileSel { int bm, bn; };
+inline TileSel pick_tile(int cout) {
+  if (cout > 64) return {128, 128};
+  if (cout > 32) return {256, 64};
+  if (cout > 16) return {256, 32};
+  return {256, 16};
+}
+
+int validate(const sfk_conv_desc* d) {
+  if (!d || !d->w) return SFK_ERR_INVALID;
+  if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
+  if (d->x.dtype != d->y.dtype || d->x.n != d->y.n) return SFK_ERR_INVALID;
+  if (d->cin != d->x.c || d->cout != d->y.c) return SFK_ERR_INVALID;
+  if (d->rt <= 0 || d->rh <= 0 || d->rw <= 0 || d->ntaps <= 0 || d->ntaps > SFK_MAX_TAPS) return SFK_ERR_INVALID;
+  if (d->wtaps <= 0) return SFK_ERR_INVALID;
+  for (int i = 0; i < d->ntaps; ++i)
+    if (d->taps[i].widx >= d->wtaps) return SFK_ERR_INVALID;
+  for (int a = 0; a < 3; ++a)
+    if (d->gs[a] <= 0 || d->os[a] <= 0 || d->oo[a] < 0) return SFK_ERR_INVALID;
+  // every scattered row must land inside y
+  if ((d->rt - 1) * d->os[0] + d->oo[0] >= d->y.t || (d->rh - 1) * d->os[1] + d->oo[1] >= d->y.h ||
+      (d->rw - 1) * d->os[2] + d->oo[2] >= d->y.w)
+    return SFK_ERR_INVALID;
+  if ((int64_t)d->x.n * d->rt * d->rh * d->rw >= (1ll << 31)) return SFK_ERR_UNSUPPORTED;
+  if (!sfk_fmap_vec_ok(&d->x)) return SFK_ERR_UNSUPPORTED;
+  if ((d->y.c % 4) || (d->y.ld % 4) || (d->y.c_off % 4) || (((uintptr_t)d->y.ptr) & 15)) return SFK_ERR_UNSUPPORTED;
+  if (((uintptr_t)d->w) & 15) return SFK_ERR_UNSUPPORTED;
+  return SFK_OK;
+}
+
+template <typename T>
+int launch(const sfk_conv_desc* d, hipStream_t s) {
+  ConvK k;
+  k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.stats = d->stats;
+  k.xt = d->x.t; k.xh = d->x.h; k.xw = d->x.w; k.xld = d->x.ld; k.xoff = d->x.c_off;
+  k.yt = d->y.t; k.yh = d->y.h; k.yw = d->y.w; k.yld = d->y.ld; k.yoff = d->y.c_off;
+  k.M = d->x.n * d->rt * d->rh * d->rw;
+  k.drw.set(d->rw); k.drh.set(d->rh); k.drt.set(d->rt);
+  k.gst = d->gs[0]; k.gsh = d->gs[1]; k.gsw = d->gs[2];
+  k.ost = d->os[0]; k.osh = d->os[1]; k.osw = d->os[2];
+  k.oot = d->oo[0]; k.ooh = d->oo[1]; k.oow = d->oo[2];
+  k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
+  k.KC = (d->cin + BK - 1) / BK;
+  k.accumulate = d->accumulate;
+  for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
+  const TileSel ts = pick_tile(d->cout);
+  k.mtiles = (k.M + ts.bm - 1) / ts.bm;
+  k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
+  const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
+  if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, k);
+  else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1>), grid, block, 0, s, k);
+  else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1>), grid, block, 0, s, k);
+  else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1>), grid, block, 0, s, k);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+}  // namespace
+
+extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
+  const int st = validate(d);
+  if (st != SFK_OK) return st;
+  const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
+  return (int)((M + pick_tile(d->cout).bm - 1) / pick_tile(d->cout).bm);
+}
+
+extern "C" int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream) {
+  const int st = validate(d);
+  if (st != SFK_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return d->x.dtype == SFK_BF16 ? launch<bf16_t>(d, s) : launch<float>(d, s);
+}

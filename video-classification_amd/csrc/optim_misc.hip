@@ -1,0 +1,231 @@
+// Fused Adam over the flat parameter arena, filter re-layout for the data-gradient pass, casts, stem im2col.
+#include "sfk_common.h"
+
+namespace {
+
+__global__ void adam_step_inc_kernel(int64_t* step) { step[0] += 1; }
+
+template <typename S>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                   float lr, float b1, float b2, float eps, float gscale,
+                                                   const int64_t* step, S* __restrict__ shadow) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)step[0];
+    bc[0] = (float)(1.0 - pow((double)b1, t));
+    bc[1] = (float)(1.0 - pow((double)b2, t));
+  }
+  __syncthreads();
+  const float step_size = lr / bc[0];
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc[1]);
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < count) {
+      float4 pv = *reinterpret_cast<float4*>(p + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 mv = *reinterpret_cast<float4*>(m + i);
+      float4 vv = *reinterpret_cast<float4*>(v + i);
+      float* pp = reinterpret_cast<float*>(&pv);
+      const float* gp = reinterpret_cast<const float*>(&gv);
+      float* mp = reinterpret_cast<float*>(&mv);
+      float* vp = reinterpret_cast<float*>(&vv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = gp[j] * gscale;
+        mp[j] = b1 * mp[j] + (1.f - b1) * gj;
+        vp[j] = b2 * vp[j] + (1.f - b2) * gj * gj;
+        pp[j] -= step_size * mp[j] / (sqrtf(vp[j]) * inv_sqrt_bc2 + eps);
+      }
+      *reinterpret_cast<float4*>(p + i) = pv;
+      *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+      if (shadow) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) shadow[i + j] = (S)pp[j];
+      }
+    } else {
+      for (int64_t e = i; e < count; ++e) {
+        const float gj = g[e] * gscale;
+        m[e] = b1 * m[e] + (1.f - b1) * gj;
+        v[e] = b2 * v[e] + (1.f - b2) * gj * gj;
+        p[e] -= step_size * m[e] / (sqrtf(v[e]) * inv_sqrt_bc2 + eps);
+        if (shadow) shadow[e] = (S)p[e];
+      }
+    }
+  }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    dst[i] = (D)(float)src[i];
+}
+
+// dst[ci][widx][co] = src[co][widx][ci]
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void filter_transpose_kernel(const S* __restrict__ src, D* __restrict__ dst,
+                                                               int cout, int wtaps, int cin) {
+  const int64_t total = (int64_t)cout * wtaps * cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i % cout);
+    const int64_t r = i / cout;
+    const int wi = (int)(r % wtaps);
+    const int ci = (int)(r / wtaps);
+    dst[i] = (D)(float)src[((int64_t)co * wtaps + wi) * cin + ci];
+  }
+}
+
+struct Im2colK {
+  const void* src;
+  int64_t sn, sc, st, sh, sw;
+  int cin, t_in, h_in, w_in;
+  const int32_t* t_index;
+  int kh, kw, sth, stw, ph, pw;
+  void* out;
+  int ot, oh, ow, oc, old, ooff;
+  int kreal;  // kh*kw*cin
+  FastDiv dcg, dow, doh, dot, dcin, dkw;
+};
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const Im2colK k, int64_t total) {
+  constexpr int VEC = DT<D>::VEC;
+  const S* sp = static_cast<const S*>(k.src);
+  D* op = static_cast<D*>(k.out);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    uint32_t pix, cg, q1, wo, q2, ho, n, t;
+    k.dcg.divmod((uint32_t)idx, pix, cg);
+    k.dow.divmod(pix, q1, wo);
+    k.doh.divmod(q1, q2, ho);
+    k.dot.divmod(q2, n, t);
+    const int frame = k.t_index ? k.t_index[t] : (int)t;
+    const S* base = sp + (int64_t)n * k.sn + (int64_t)frame * k.st;
+    Vec16<D> o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int col = (int)cg * VEC + i;
+      float f = 0.f;
+      if (col < k.kreal && (unsigned)frame < (unsigned)k.t_in) {
+        uint32_t tapi, ci, khi, kwi;
+        k.dcin.divmod((uint32_t)col, tapi, ci);
+        k.dkw.divmod(tapi, khi, kwi);
+        const int hi = (int)ho * k.sth - k.ph + (int)khi, wi = (int)wo * k.stw - k.pw + (int)kwi;
+        if ((unsigned)hi < (unsigned)k.h_in && (unsigned)wi < (unsigned)k.w_in)
+          f = (float)base[(int64_t)ci * k.sc + (int64_t)hi * k.sh + (int64_t)wi * k.sw];
+      }
+      o.set(i, f);
+    }
+    o.store(op + (int64_t)pix * k.old + k.ooff + cg * VEC);
+  }
+}
+
+inline unsigned grid_for(int64_t total, int per_thread = 1) {
+  int64_t b = (total + 256ll * per_thread - 1) / (256ll * per_thread);
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int sfk_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                        float beta2, float eps, float grad_scale, int64_t* step, void* shadow,
+                        int32_t shadow_dtype, sfk_stream_t stream) {
+  if (!p || !g || !m || !v || !step || count <= 0) return SFK_ERR_INVALID;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return SFK_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+  const dim3 grid(grid_for(count, 4)), blk(256);
+  if (shadow && shadow_dtype == SFK_BF16)
+    hipLaunchKernelGGL(adam_kernel<bf16_t>, grid, blk, 0, s, p, g, m, v, count, lr, beta1, beta2, eps, grad_scale, step, static_cast<bf16_t*>(shadow));
+  else
+    hipLaunchKernelGGL(adam_kernel<float>, grid, blk, 0, s, p, g, m, v, count, lr, beta1, beta2, eps, grad_scale, step, static_cast<float*>(shadow));
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+
+static inline bool dtype_ok(int d) { return d == SFK_F32 || d == SFK_BF16; }
+
+extern "C" int sfk_filter_transpose(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int32_t cout,
+                                    int32_t wtaps, int32_t cin, sfk_stream_t stream) {
+  if (!src || !dst || cout <= 0 || wtaps <= 0 || cin <= 0 || !dtype_ok(src_dtype) || !dtype_ok(dst_dtype))
+    return SFK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)cout * wtaps * cin;
+  if (src_dtype == SFK_F32 && dst_dtype == SFK_F32)
+    hipLaunchKernelGGL((filter_transpose_kernel<float, float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, (float*)dst, cout, wtaps, cin);
+  else if (src_dtype == SFK_F32 && dst_dtype == SFK_BF16)
+    hipLaunchKernelGGL((filter_transpose_kernel<float, bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, cout, wtaps, cin);
+  else if (src_dtype == SFK_BF16 && dst_dtype == SFK_F32)
+    hipLaunchKernelGGL((filter_transpose_kernel<bf16_t, float>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, cout, wtaps, cin);
+  else
+    hipLaunchKernelGGL((filter_transpose_kernel<bf16_t, bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, cout, wtaps, cin);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count,
+                        sfk_stream_t stream) {
+  if (!src || !dst || count <= 0 || !dtype_ok(src_dtype) || !dtype_ok(dst_dtype)) return SFK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (src_dtype == SFK_F32 && dst_dtype == SFK_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid_for(count, 4)), dim3(256), 0, s, (const float*)src, (float*)dst, count);
+  else if (src_dtype == SFK_F32 && dst_dtype == SFK_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid_for(count, 4)), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, count);
+  else if (src_dtype == SFK_BF16 && dst_dtype == SFK_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid_for(count, 4)), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, count);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid_for(count, 4)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, count);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream) {
+  if (!p) return SFK_ERR_INVALID;
+  if (bytes == 0) return SFK_OK;
+  return hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream)) == hipSuccess ? SFK_OK : SFK_ERR_LAUNCH;
+}
+
+extern "C" int sfk_stem_im2col(const sfk_im2col_desc* d, sfk_stream_t stream) {
+  if (!d || !d->src || !sfk_fmap_ok(&d->out) || !dtype_ok(d->src_dtype)) return SFK_ERR_INVALID;
+  if (d->cin <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0)
+    return SFK_ERR_INVALID;
+  if (d->out.c < d->kh * d->kw * d->cin) return SFK_ERR_INVALID;
+  if (d->out.h != (d->h_in + 2 * d->pad_h - d->kh) / d->stride_h + 1 ||
+      d->out.w != (d->w_in + 2 * d->pad_w - d->kw) / d->stride_w + 1)
+    return SFK_ERR_INVALID;
+  if (!d->t_index && d->out.t != d->t_in) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(&d->out)) return SFK_ERR_UNSUPPORTED;
+  const int vec = sfk_vec_of(d->out.dtype);
+  const int64_t total = sfk_fmap_pixels(&d->out) * (d->out.c / vec);
+  if (total >= (1ll << 31)) return SFK_ERR_UNSUPPORTED;
+  Im2colK k;
+  k.src = d->src; k.sn = d->sn; k.sc = d->sc; k.st = d->st; k.sh = d->sh; k.sw = d->sw;
+  k.cin = d->cin; k.t_in = d->t_in; k.h_in = d->h_in; k.w_in = d->w_in; k.t_index = d->t_index;
+  k.kh = d->kh; k.kw = d->kw; k.sth = d->stride_h; k.stw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
+  k.out = d->out.ptr; k.ot = d->out.t; k.oh = d->out.h; k.ow = d->out.w; k.oc = d->out.c; k.old = d->out.ld;
+  k.ooff = d->out.c_off; k.kreal = d->kh * d->kw * d->cin;
+  k.dcg.set(d->out.c / vec); k.dow.set(d->out.w); k.doh.set(d->out.h); k.dot.set(d->out.t);
+  k.dcin.set(d->cin); k.dkw.set(d->kw);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(total)), blk(256);
+  if (d->src_dtype == SFK_F32 && d->out.dtype == SFK_F32) hipLaunchKernelGGL((stem_im2col_kernel<float, float>), grid, blk, 0, s, k, total);
+  else if (d->src_dtype == SFK_F32 && d->out.dtype == SFK_BF16) hipLaunchKernelGGL((stem_im2col_kernel<float, bf16_t>), grid, blk, 0, s, k, total);
+  else if (d->src_dtype == SFK_BF16 && d->out.dtype == SFK_F32) hipLaunchKernelGGL((stem_im2col_kernel<bf16_t, float>), grid, blk, 0, s, k, total);
+  else hipLaunchKernelGGL((stem_im2col_kernel<bf16_t, bf16_t>), grid, blk, 0, s, k, total);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_abi_version(void) { return SFK_ABI_VERSION; }
+
+extern "C" const char* sfk_status_string(int status) {
+  switch (status) {
+    case SFK_OK: return "ok";
+    case SFK_ERR_INVALID: return "invalid argument";
+    case SFK_ERR_UNSUPPORTED: return "unsupported shape or alignment";
+    case SFK_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}

@@ -1,0 +1,78 @@
+// Shared device/host helpers for libsfk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sfk.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SFK_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return SFK_ERR_LAUNCH; \
+  } while (0)
+
+// q = n / d for 0 <= n < 2^31, d >= 1, via one mul-high (divisions by runtime extents are hot in the gathers)
+struct FastDiv {
+  uint32_t mul, shr, d;
+  __host__ void set(int32_t denom) {
+    d = (uint32_t)denom;
+    if (denom <= 1) { mul = 0; shr = 0; return; }
+    uint32_t lg = 0;
+    while ((1u << lg) < (uint32_t)denom) ++lg;
+    uint32_t p = 31 + lg;
+    uint64_t m = ((1ull << p) + (uint64_t)denom - 1) / (uint64_t)denom;
+    mul = (uint32_t)m;
+    shr = p - 32;
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return d <= 1 ? n : (__umulhi(n, mul) >> shr); }
+  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+    q = div(n);
+    r = n - q * d;
+  }
+};
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int code = SFK_F32;
+  static constexpr int VEC = 4;  // elements per 16 bytes
+};
+template <> struct DT<bf16_t> {
+  static constexpr int code = SFK_BF16;
+  static constexpr int VEC = 8;
+};
+
+// 16-byte vector of T <-> float[VEC]
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  float4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ float get(int i) const { return reinterpret_cast<const float*>(&v)[i]; }
+  __device__ __forceinline__ void set(int i, float f) { reinterpret_cast<float*>(&v)[i] = f; }
+  __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct Vec16<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
+  __device__ __forceinline__ void zero() {
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+  }
+};
+
+static inline bool sfk_fmap_ok(const sfk_fmap* f) {
+  return f && f->ptr && f->n > 0 && f->t > 0 && f->h > 0 && f->w > 0 && f->c > 0 && f->ld >= f->c_off + f->c &&
+         f->c_off >= 0 && (f->dtype == SFK_F32 || f->dtype == SFK_BF16);
+}
+static inline int sfk_vec_of(int dtype) { return dtype == SFK_BF16 ? 8 : 4; }
+static inline bool sfk_fmap_vec_ok(const sfk_fmap* f) {
+  const int v = sfk_vec_of(f->dtype);
+  return (f->c % v) == 0 && (f->ld % v) == 0 && (f->c_off % v) == 0 && (((uintptr_t)f->ptr) & 15) == 0;
+}
+static inline int64_t sfk_fmap_pixels(const sfk_fmap* f) { return (int64_t)f->n * f->t * f->h * f->w; }

@@ -1,0 +1,605 @@
+"""SlowFast execution engine: one flat list of C-ABI kernel calls per forward / backward, on one hipStream.
+
+What replaces what (reference file:line):
+  forward            model(x) at train.py:226,306  (pytorchvideo Net.forward over blocks.0..6)
+  backward           loss.backward() at train.py:230
+  lateral fusion     FuseFastToSlow.forward, model/my_slowfast.py:334-344 -- the fused branch is written straight into
+                     the channel slice [C_slow, C_slow+C_fuse) of the slow pathway's buffer, so torch.cat (:343) vanishes
+  parameters         one fp32 arena (master weights) + one fp32 gradient arena; conv filters are kept in the kernels'
+                     [cout][tap][cin] layout and converted to/from the reference (cout,cin,kt,kh,kw) layout only in
+                     state_dict()/load_state_dict() (train.py:192,212 checkpoint surface, pytorchvideo key names)
+Data layout in HBM: channels-last feature maps (N,T,H,W,C) with an explicit pixel stride (include/sfk.h), bf16 or f32;
+per-channel statistics, master weights, gradients and the head are fp32.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import arch
+from ._lib import ConvPass, FMap, Im2col, WgradPass
+from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
+
+Run = Callable[[int], None]
+MAX_PARTS = 2048
+
+
+@dataclass
+class _Layer:
+    cb: arch.ConvBN
+    eg: ConvGeom              # geometry the kernels see (stems: temporal conv over the im2col patch matrix)
+    kreal: int                # stems: kh*kw*cin before padding, else 0
+    w_off: int = 0
+    w_numel: int = 0
+    g_off: int = 0
+    b_off: int = 0
+    needs_dgrad: bool = True
+    rm: torch.Tensor = None
+    rv: torch.Tensor = None
+    nbt: torch.Tensor = None
+
+    @property
+    def c(self) -> int:
+        return self.eg.cout
+
+
+@dataclass
+class _UnitRec:
+    """What the backward of one conv+BN unit needs from its forward."""
+    L: _Layer
+    x: FMap
+    y: FMap
+    mean: torch.Tensor
+    invstd: torch.Tensor
+    scale: torch.Tensor
+    shift: torch.Tensor
+
+
+class Plan:
+    def __init__(self):
+        self.fwd: List[Run] = []
+        self.bwd: List[Run] = []
+        self.logits: torch.Tensor = None
+        self.dlogits: torch.Tensor = None
+        self.key = None
+
+
+class Engine:
+    def __init__(self, spec: arch.SlowFastSpec, dtype: torch.dtype = torch.bfloat16, device="cuda", backend=None,
+                 seed: int = 0):
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.spec, self.dtype, self.device = spec, dtype, torch.device(device)
+        if backend is None:
+            from ._lib import HipBackend
+            backend = HipBackend()        # raises if libsfk.so is missing: no fallback path exists
+        self.be = backend
+        self.wiring = arch.build_wiring(spec)
+        self.vec = 8                      # channel alignment both precisions are built for
+        self._layers: Dict[str, _Layer] = {}
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._plans: Dict[tuple, Plan] = {}
+        self._build_params(seed)
+        self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
+
+    # ------------------------------------------------------------------ parameters
+    def _new(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _build_params(self, seed: int):
+        W = self.wiring
+        off = 0
+        layers: List[_Layer] = []
+        for cb in W.all_convbn():
+            g = cb.geom
+            if cb.is_stem:
+                kreal = g.k[1] * g.k[2] * g.cin
+                kpad = round_up(kreal, self.vec)
+                eg = ConvGeom(kpad, g.cout, (g.k[0], 1, 1), (1, 1, 1), (g.k[0] // 2, 0, 0))
+                L = _Layer(cb, eg, kreal, needs_dgrad=False)
+            else:
+                assert g.cin % self.vec == 0 and g.cout % 4 == 0, (cb.conv_key, g)
+                L = _Layer(cb, g, 0)
+            L.w_off, L.w_numel = off, L.eg.cout * L.eg.wtaps * L.eg.cin
+            off += round_up(L.w_numel, self.vec)
+            layers.append(L)
+            self._layers[cb.conv_key] = L
+        self.conv_total = off
+        self.fc_w_off = off
+        self.fc_in, self.fc_out = W.head_in, self.spec.num_class
+        off += round_up(self.fc_in * self.fc_out, self.vec)
+        self.fc_b_off = off
+        off += round_up(self.fc_out, self.vec)
+        for L in layers:
+            L.g_off = off
+            off += round_up(L.c, self.vec)
+            L.b_off = off
+            off += round_up(L.c, self.vec)
+        self.layers = layers
+        self.arena_numel = off
+        self.P = torch.nn.Parameter(self._new(off), requires_grad=True)
+        self.G = self._new(off)
+        self.adam_m = None
+        self.adam_v = None
+        self.adam_step = None
+        # compute-precision copies of the filters: S = [cout][tap][cin] (forward, filter-gradient layout),
+        # St = [cin][tap][cout] (data-gradient pass)
+        self.S = self.P.data if self.dtype == torch.float32 else self._new(self.conv_total, dtype=self.dtype)
+        self.St = self._new(self.conv_total, dtype=self.dtype)
+        for L in layers:
+            L.rm = self._new(L.c)
+            L.rv = torch.ones(L.c, dtype=torch.float32, device=self.device)
+            L.nbt = self._new(1, dtype=torch.int64)
+        self.dead: Dict[str, torch.Tensor] = {}
+        self.reset_parameters(seed)
+
+    def reset_parameters(self, seed: int = 0):
+        """'resnet' init of the reference stack: conv Kaiming-normal(fan_out), BN weight 1
+        (0 for the block-final BN), BN bias 0, Linear N(0, 0.01) / bias 0."""
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        P = self.P.data
+        P.zero_()
+        for L in self.layers:
+            g = L.cb.geom
+            std = math.sqrt(2.0 / (g.cout * g.wtaps))
+            w = torch.randn(g.cout, g.cin, *g.k, generator=gen) * std
+            P[L.w_off:L.w_off + L.w_numel] = self._to_engine_layout(L, w).to(self.device)
+            P[L.g_off:L.g_off + L.c] = 0.0 if L.cb.zero_init_gamma else 1.0
+            L.rm.zero_()
+            L.rv.fill_(1.0)
+            L.nbt.zero_()
+        P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out] = (
+            torch.randn(self.fc_out * self.fc_in, generator=gen) * 0.01).to(self.device)
+        for d in self.wiring.dead:
+            if d.kind == "conv_w":
+                fan_out = d.shape[0] * d.shape[2] * d.shape[3] * d.shape[4]
+                t = torch.randn(*d.shape, generator=gen) * math.sqrt(2.0 / fan_out)
+            elif d.kind in ("bn_w", "bn_rv"):
+                t = torch.ones(*d.shape)
+            elif d.kind == "bn_nbt":
+                t = torch.zeros((), dtype=torch.int64)
+            else:
+                t = torch.zeros(*d.shape)
+            self.dead[d.key] = t.to(self.device)
+
+    def _to_engine_layout(self, L: _Layer, w: torch.Tensor) -> torch.Tensor:
+        """(cout, cin, kt, kh, kw) -> flat [cout][tap][cin]  (stems: [cout][kt][(kh,kw,cin) zero-padded])."""
+        g = L.cb.geom
+        w = w.reshape(g.cout, g.cin, *g.k).permute(0, 2, 3, 4, 1)  # co, kt, kh, kw, ci
+        if L.cb.is_stem:
+            w = w.reshape(g.cout, g.k[0], L.kreal)
+            w = torch.nn.functional.pad(w, (0, L.eg.cin - L.kreal))
+        return w.reshape(-1).float()
+
+    def _from_engine_layout(self, L: _Layer, flat: torch.Tensor) -> torch.Tensor:
+        g = L.cb.geom
+        if L.cb.is_stem:
+            w = flat.reshape(g.cout, g.k[0], L.eg.cin)[..., :L.kreal].reshape(g.cout, g.k[0], g.k[1], g.k[2], g.cin)
+        else:
+            w = flat.reshape(g.cout, g.k[0], g.k[1], g.k[2], g.cin)
+        return w.permute(0, 4, 1, 2, 3).contiguous()
+
+    # checkpoint surface: flat dict with pytorchvideo key names, fp32, reference tensor shapes
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd: Dict[str, torch.Tensor] = {}
+        P = self.P.data
+        for L in self.layers:
+            sd[L.cb.conv_key + ".weight"] = self._from_engine_layout(L, P[L.w_off:L.w_off + L.w_numel]).clone()
+            nk = L.cb.norm_key
+            sd[nk + ".weight"] = P[L.g_off:L.g_off + L.c].clone()
+            sd[nk + ".bias"] = P[L.b_off:L.b_off + L.c].clone()
+            sd[nk + ".running_mean"] = L.rm.clone()
+            sd[nk + ".running_var"] = L.rv.clone()
+            sd[nk + ".num_batches_tracked"] = L.nbt[0].clone()
+        sd["blocks.6.proj.weight"] = P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out].reshape(
+            self.fc_out, self.fc_in).clone()
+        sd["blocks.6.proj.bias"] = P[self.fc_b_off:self.fc_b_off + self.fc_out].clone()
+        for k, v in self.dead.items():
+            sd[k] = v.clone()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        bad = [k for k in own if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+        if bad:
+            raise RuntimeError("size mismatch for " + ", ".join(bad))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        P = self.P.data
+        dev = self.device
+
+        def get(k):
+            return sd[k].to(dev) if k in sd else None
+
+        with torch.no_grad():
+            for L in self.layers:
+                w = get(L.cb.conv_key + ".weight")
+                if w is not None:
+                    P[L.w_off:L.w_off + L.w_numel] = self._to_engine_layout(L, w.float())
+                nk = L.cb.norm_key
+                for suffix, dst in ((".weight", P[L.g_off:L.g_off + L.c]), (".bias", P[L.b_off:L.b_off + L.c]),
+                                    (".running_mean", L.rm), (".running_var", L.rv)):
+                    v = get(nk + suffix)
+                    if v is not None:
+                        dst.copy_(v.float())
+                v = get(nk + ".num_batches_tracked")
+                if v is not None:
+                    L.nbt.fill_(int(v))
+            v = get("blocks.6.proj.weight")
+            if v is not None:
+                P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out] = v.float().reshape(-1)
+            v = get("blocks.6.proj.bias")
+            if v is not None:
+                P[self.fc_b_off:self.fc_b_off + self.fc_out] = v.float()
+            for k in self.dead:
+                if k in sd:
+                    self.dead[k] = sd[k].to(dev).clone()
+
+        class _Keys:
+            missing_keys = missing
+            unexpected_keys = unexpected
+        return _Keys()
+
+    def num_parameters(self, live_only: bool = False) -> int:
+        n = sum(L.cb.geom.cout * L.cb.geom.cin * L.cb.geom.wtaps + 2 * L.c for L in self.layers)
+        n += self.fc_in * self.fc_out + self.fc_out
+        if not live_only:
+            n += sum(int(v.numel()) for k, v in self.dead.items()
+                     if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+        return n
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, tag: str, numel: int, dtype=None) -> torch.Tensor:
+        dtype = self.dtype if dtype is None else dtype
+        key = f"{tag}|{dtype}"
+        t = self._bufs.get(key)
+        if t is None or t.numel() < numel:
+            t = torch.zeros(max(numel, 1), dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _fmap(self, tag: str, n, t, h, w, c, ld=None) -> FMap:
+        ld = c if ld is None else ld
+        return FMap(self._buf(tag, n * t * h * w * ld), n, t, h, w, c, ld, 0)
+
+    def _pslice(self, off: int, n: int) -> torch.Tensor:
+        return self.P.data[off:off + n]
+
+    def _gslice(self, off: int, n: int) -> torch.Tensor:
+        return self.G[off:off + n]
+
+    # ------------------------------------------------------------------ plan construction
+    def _conv(self, pl: Plan, L: _Layer, x: FMap, y: FMap, stats_tag: Optional[str]):
+        """forward conv pass x -> y (+ BatchNorm partial statistics when stats_tag). returns (stats, mtiles)"""
+        sp = fwd_pass(L.eg, (x.t, x.h, x.w))
+        w = self.S[L.w_off:L.w_off + L.w_numel]
+        p = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, L.eg.wtaps, L.eg.cin, L.eg.cout)
+        stats, mt = None, 0
+        if stats_tag is not None:
+            mt = self.be.conv_igemm_mtiles(p)
+            stats = self._buf(stats_tag, mt * L.c * 2, torch.float32)
+            p.stats = stats
+        pl.fwd.append(self.be.conv_igemm(p))
+        return stats, mt
+
+    def _unit_fwd(self, pl: Plan, L: _Layer, x: FMap, tag: str, train: bool, n: int):
+        """conv + BatchNorm coefficients.  returns (y, scale, shift, rec)"""
+        od = L.eg.out_dims((x.t, x.h, x.w))
+        y = self._fmap(f"y.{tag}", n, od[0], od[1], od[2], L.c)
+        scale = self._buf(f"scale.{tag}", L.c, torch.float32)
+        shift = self._buf(f"shift.{tag}", L.c, torch.float32)
+        gamma, beta = self._pslice(L.g_off, L.c), self._pslice(L.b_off, L.c)
+        rec = None
+        if train:
+            stats, mt = self._conv(pl, L, x, y, f"stats.{tag}")
+            mean = self._buf(f"mean.{tag}", L.c, torch.float32)
+            invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
+            pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
+                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift))
+            rec = _UnitRec(L, x, y, mean, invstd, scale, shift)
+        else:
+            self._conv(pl, L, x, y, None)
+            pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, L.rm, L.rv, self.spec.bn_eps, L.c, scale, shift))
+        return y, scale, shift, rec
+
+    def _bn_bwd(self, pl: Plan, rec: _UnitRec, da: FMap, tag: str, relu: bool, mask_src: Optional[FMap],
+                dz_inplace: bool, dy: FMap):
+        """BatchNorm(+ReLU) backward of one unit: da -> dy (may alias da), accumulates dgamma/dbeta."""
+        L = rec.L
+        parts = self._buf(f"bparts.{tag}", MAX_PARTS * L.c * 2, torch.float32)
+        coef = self._buf(f"coef.{tag}", L.c * 3, torch.float32)
+        run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
+                                         da if dz_inplace else None, parts, MAX_PARTS)
+        pl.bwd.append(run)
+        pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
+                                              self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef))
+        if dz_inplace:   # the mask is already applied to da
+            pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False,
+                                               coef, dy))
+        else:
+            pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
+                                               coef, dy))
+
+    def _wgrad(self, pl: Plan, rec: _UnitRec, dy: FMap):
+        L = rec.L
+        pl.bwd.append(self.be.conv_wgrad(WgradPass(rec.x, dy, L.eg.s, list(wgrad_taps(L.eg)),
+                                                   self._gslice(L.w_off, L.w_numel), L.eg.wtaps, L.eg.cin, L.eg.cout)))
+
+    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool):
+        """data gradient of rec's conv: dy -> dx (+= when accumulate)."""
+        L = rec.L
+        assert L.needs_dgrad
+        passes, needs_zero = dgrad_passes(L.eg, (rec.x.t, rec.x.h, rec.x.w))
+        if needs_zero and not accumulate:
+            assert dx.ld == dx.c and dx.c_off == 0, "zero-fill of a channel slice is not supported"
+            pl.bwd.append(self.be.fill_zero(dx.buf[: dx.pixels * dx.ld]))
+        wt = self.St[L.w_off:L.w_off + L.w_numel]
+        for sp in passes:
+            pl.bwd.append(self.be.conv_igemm(ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt,
+                                                      L.eg.wtaps, L.eg.cout, L.eg.cin, accumulate=accumulate)))
+
+    # ---- stem: im2col -> temporal conv -> BN -> ReLU -> MaxPool
+    def _stem_fwd(self, pl, p: int, x5: torch.Tensor, t_index, out: FMap, train: bool):
+        L = self._layers[self.wiring.stems[p].conv_key]
+        g = L.cb.geom
+        n, _, t_in, h_in, w_in = x5.shape
+        t_out = t_in if t_index is None else int(t_index.numel())
+        ho = (h_in + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
+        wo = (w_in + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
+        cols = self._fmap(f"cols.{p}", n, t_out, ho, wo, L.eg.cin)
+        pl.fwd.append(self.be.stem_im2col(Im2col(x5, t_index, g.k[1], g.k[2], (g.s[1], g.s[2]), (g.p[1], g.p[2]), cols)))
+        y, scale, shift, rec = self._unit_fwd(pl, L, cols, f"stem{p}", train, n)
+        a = self._fmap(f"a.stem{p}", n, y.t, y.h, y.w, L.c)
+        pl.fwd.append(self.be.bn_apply(y, scale, shift, None, None, None, True, a))
+        assert (out.h, out.w) == ((a.h + 2 - 3) // 2 + 1, (a.w + 2 - 3) // 2 + 1) and out.t == a.t
+        argmax = self._buf(f"argmax.{p}", out.pixels * L.c, torch.uint8)
+        pl.fwd.append(self.be.maxpool_fwd(a, out, argmax, 3, 2, 1))
+        return (rec, a, argmax, out)
+
+    def _stem_bwd(self, pl, p: int, srec, d_out: FMap):
+        rec, a, argmax, out = srec
+        da = self._fmap(f"da.stem{p}", a.n, a.t, a.h, a.w, a.c)
+        pl.bwd.append(self.be.maxpool_bwd(d_out, argmax, da, 3, 2, 1))
+        self._bn_bwd(pl, rec, da, f"stem{p}", True, None, False, da)
+        self._wgrad(pl, rec, da)
+
+    # ---- lateral fusion: conv over the fast pathway -> BN -> ReLU -> channel slice of the slow buffer
+    def _fusion_fwd(self, pl, bi: int, xf: FMap, out_slice: FMap, train: bool):
+        L = self._layers[self.wiring.fusions[bi].conv_key]
+        y, scale, shift, rec = self._unit_fwd(pl, L, xf, f"fuse{bi}", train, xf.n)
+        assert (y.t, y.h, y.w, y.c) == (out_slice.t, out_slice.h, out_slice.w, out_slice.c), \
+            "lateral fusion: fast pathway does not line up with the slow pathway (T_fast / stride != T_slow?)"
+        pl.fwd.append(self.be.bn_apply(y, scale, shift, None, None, None, True, out_slice))
+        return rec
+
+    def _fusion_bwd(self, pl, bi: int, rec: _UnitRec, d_slice: FMap, d_xf: FMap):
+        dy = self._fmap(f"dy.fuse{bi}", rec.y.n, rec.y.t, rec.y.h, rec.y.w, rec.y.c)
+        self._bn_bwd(pl, rec, d_slice, f"fuse{bi}", True, None, False, dy)
+        self._wgrad(pl, rec, dy)
+        self._dgrad(pl, rec, dy, d_xf, accumulate=True)
+
+    # ---- bottleneck residual block
+    def _block_fwd(self, pl, blk: arch.Block, x: FMap, out: FMap, tag: str, train: bool):
+        n = x.n
+        La, Lb, Lc = (self._layers[b.conv_key] for b in (blk.conv_a, blk.conv_b, blk.conv_c))
+        rec1 = None
+        y1 = s1 = h1 = None
+        if blk.branch1 is not None:
+            L1 = self._layers[blk.branch1.conv_key]
+            y1, s1, h1, rec1 = self._unit_fwd(pl, L1, x, f"{tag}.b1", train, n)
+        ya, sa, ha, reca = self._unit_fwd(pl, La, x, f"{tag}.a", train, n)
+        aa = self._fmap(f"a.{tag}.a", n, ya.t, ya.h, ya.w, La.c)
+        pl.fwd.append(self.be.bn_apply(ya, sa, ha, None, None, None, True, aa))
+        yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n)
+        ab = self._fmap(f"a.{tag}.b", n, yb.t, yb.h, yb.w, Lb.c)
+        pl.fwd.append(self.be.bn_apply(yb, sb, hb, None, None, None, True, ab))
+        yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n)
+        assert (yc.t, yc.h, yc.w, yc.c) == (out.t, out.h, out.w, out.c)
+        if blk.branch1 is not None:
+            pl.fwd.append(self.be.bn_apply(yc, sc, hc, y1, s1, h1, True, out))
+        else:
+            pl.fwd.append(self.be.bn_apply(yc, sc, hc, x, None, None, True, out))
+        return (blk, tag, x, out, rec1, reca, recb, recc)
+
+    def _block_bwd(self, pl, brec, d_out: FMap) -> FMap:
+        """d_out: gradient w.r.t. the block output (clobbered).  returns the gradient w.r.t. the block input."""
+        blk, tag, x, out, rec1, reca, recb, recc = brec
+        n = x.n
+        # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
+        dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
+        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc)
+        self._wgrad(pl, recc, dyc)
+        dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
+        self._dgrad(pl, recc, dyc, dab, accumulate=False)
+        self._bn_bwd(pl, recb, dab, f"{tag}.b", True, None, False, dab)
+        self._wgrad(pl, recb, dab)
+        daa = self._fmap(f"da.{tag}.a", n, reca.y.t, reca.y.h, reca.y.w, reca.y.c)
+        self._dgrad(pl, recb, dab, daa, accumulate=False)
+        self._bn_bwd(pl, reca, daa, f"{tag}.a", True, None, False, daa)
+        self._wgrad(pl, reca, daa)
+        if rec1 is None:
+            # identity shortcut: dX = dz + dgrad_a
+            self._dgrad(pl, reca, daa, d_out, accumulate=True)
+            return d_out
+        dx = self._fmap(f"dx.{tag}", n, x.t, x.h, x.w, x.c)
+        self._dgrad(pl, reca, daa, dx, accumulate=False)
+        self._bn_bwd(pl, rec1, d_out, f"{tag}.b1", False, None, False, d_out)   # d_out already holds dz
+        self._wgrad(pl, rec1, d_out)
+        self._dgrad(pl, rec1, d_out, dx, accumulate=True)
+        return dx
+
+    def _build_plan(self, x_slow: torch.Tensor, x_fast: torch.Tensor, slow_t_index, train: bool) -> Plan:
+        be, spec, W = self.be, self.spec, self.wiring
+        pl = Plan()
+        n = x_fast.shape[0]
+        # ---- refresh the compute-precision filter copies from the fp32 master arena
+        if self.dtype != torch.float32:
+            pl.fwd.append(be.cast(self.P.data, self.S, self.conv_total))
+        if train:
+            for L in self.layers:
+                if L.needs_dgrad:
+                    pl.fwd.append(be.filter_transpose(self.S[L.w_off:L.w_off + L.w_numel],
+                                                      self.St[L.w_off:L.w_off + L.w_numel], L.eg.cout, L.eg.wtaps,
+                                                      L.eg.cin))
+        # ---- geometry after the stems
+        def stem_out(x5, p, t_idx):
+            g = W.stems[p].geom
+            t = x5.shape[2] if t_idx is None else int(t_idx.numel())
+            t = (t + 2 * g.p[0] - g.k[0]) // g.s[0] + 1
+            h = (x5.shape[3] + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
+            w = (x5.shape[4] + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
+            return t, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        ts, hs, ws = stem_out(x_slow, 0, slow_t_index)
+        tf, hf, wf = stem_out(x_fast, 1, None)
+        c_s, c_f = spec.stem_dim_outs
+        fuse = spec.fuse
+
+        def slow_buffer(tag, t, h, w, c, bi):
+            """slow pathway activation of block index bi; wide enough to also hold the fused fast channels"""
+            extra = W.fusions[bi].geom.cout if (fuse and bi < 4 and W.fusions[bi] is not None) else 0
+            full = self._fmap(tag, n, t, h, w, c + extra)
+            return full, full.channels(0, c)
+
+        cat0, s0 = slow_buffer("cat.0", ts, hs, ws, c_s, 0)
+        xf = self._fmap("xf.0", n, tf, hf, wf, c_f)
+        stem_recs = [self._stem_fwd(pl, 0, x_slow, slow_t_index, s0, train),
+                     self._stem_fwd(pl, 1, x_fast, None, xf, train)]
+        fusion_recs = [None] * 4
+        if fuse:
+            fusion_recs[0] = self._fusion_fwd(pl, 0, xf, cat0.channels(c_s, cat0.c - c_s), train)
+        xs_full = cat0
+        stage_recs = []
+        xs_fulls, xfs = [cat0], [xf]
+        for si in range(4):
+            recs_sp = []
+            for p in range(2):
+                blocks = W.stages[si][p]
+                x = xs_full if p == 0 else xf
+                brecs = []
+                for i, blk in enumerate(blocks):
+                    od = blk.conv_b.geom.out_dims((x.t, x.h, x.w))
+                    cout = blk.conv_c.geom.cout
+                    last = i == len(blocks) - 1
+                    tag = f"s{si}p{p}b{i}"
+                    if p == 0 and last:
+                        full, out = slow_buffer(f"cat.{si + 1}", od[0], od[1], od[2], cout, si + 1)
+                    else:
+                        full = out = self._fmap(f"out.{tag}", n, od[0], od[1], od[2], cout)
+                    brecs.append(self._block_fwd(pl, blk, x, out, tag, train))
+                    x = out
+                    if p == 0 and last:
+                        xs_full_next = full
+                recs_sp.append(brecs)
+                if p == 1:
+                    xf = x
+            xs_full = xs_full_next
+            c_slow = W.stages[si][0][-1].conv_c.geom.cout
+            if fuse and si < 3:
+                fusion_recs[si + 1] = self._fusion_fwd(pl, si + 1, xf, xs_full.channels(c_slow, xs_full.c - c_slow),
+                                                       train)
+            stage_recs.append(recs_sp)
+            xs_fulls.append(xs_full)
+            xfs.append(xf)
+        # ---- head
+        xs_out, xf_out = xs_full, xf
+        F = self.fc_in
+        feat = self._buf("feat", n * F, torch.float32)
+        rate = float(spec.dropout) if train else 0.0
+        ks, kf = spec.head_pool_kernels
+        pl.fwd.append(be.head_pool_fwd(xs_out, ks, rate, self.drop_seed, feat, F, 0))
+        pl.fwd.append(be.head_pool_fwd(xf_out, kf, rate, self.drop_seed, feat, F, xs_out.c))
+        assert xs_out.c + xf_out.c == F
+        K = self.fc_out
+        pl.logits = self._buf("logits", n * K, torch.float32)[: n * K].view(n, K)
+        fcw, fcb = self._pslice(self.fc_w_off, F * K), self._pslice(self.fc_b_off, K)
+        pl.fwd.append(be.fc_fwd(feat, fcw, fcb, pl.logits, n, F, K))
+        if not train:
+            return pl
+
+        # ================================================================= backward schedule
+        pl.dlogits = self._buf("dlogits", n * K, torch.float32)[: n * K].view(n, K)
+        dfeat = self._buf("dfeat", n * F, torch.float32)
+        pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, self._gslice(self.fc_w_off, F * K),
+                                self._gslice(self.fc_b_off, K), n, F, K))
+        d_xs = self._fmap("d.cat.4", n, xs_out.t, xs_out.h, xs_out.w, xs_out.c)
+        d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
+        pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
+        pl.bwd.append(be.head_pool_bwd(dfeat, F, xs_out.c, kf, rate, self.drop_seed, d_xf))
+        for si in range(3, -1, -1):
+            # slow pathway of this stage: d_xs is the gradient of its last block's output
+            d = d_xs
+            for brec in reversed(stage_recs[si][0]):
+                d = self._block_bwd(pl, brec, d)
+            d_cat = d                                   # gradient of the (concatenated) slow input of this stage
+            d = d_xf
+            for brec in reversed(stage_recs[si][1]):
+                d = self._block_bwd(pl, brec, d)
+            d_xf = d
+            c_prev = xs_fulls[si].c - (W.fusions[si].geom.cout if fuse else 0)
+            if fuse:
+                self._fusion_bwd(pl, si, fusion_recs[si], d_cat.channels(c_prev, d_cat.c - c_prev), d_xf)
+            d_xs = d_cat.channels(0, c_prev)
+        self._stem_bwd(pl, 0, stem_recs[0], d_xs)
+        self._stem_bwd(pl, 1, stem_recs[1], d_xf)
+        return pl
+
+    # ------------------------------------------------------------------ execution
+    def _plan_for(self, x_slow, x_fast, slow_t_index, train: bool) -> Plan:
+        def sig(t):
+            return None if t is None else (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+        key = (sig(x_slow), sig(x_fast), sig(slow_t_index), train)
+        pl = self._plans.get(key)
+        if pl is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            pl = self._build_plan(x_slow, x_fast, slow_t_index, train)
+            pl.key = key
+            pl.inputs = (x_slow, x_fast, slow_t_index)   # keep the bound tensors alive
+            self._plans[key] = pl
+        return pl
+
+    def _stream(self) -> int:
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    @staticmethod
+    def _run(ops: List[Run], stream: int):
+        for op in ops:
+            op(stream)
+
+    def forward(self, x_slow: torch.Tensor, x_fast: torch.Tensor, train: bool, slow_t_index=None) -> Plan:
+        """x_*: (N, C, T, H, W) views with ANY strides (the dataset's N,T,C,H,W memory is read in place).
+        If slow_t_index is given, the slow pathway reads frames x_slow[:, :, slow_t_index] (PackPathway)."""
+        assert x_slow.dim() == 5 and x_fast.dim() == 5 and x_slow.shape[0] == x_fast.shape[0]
+        assert x_slow.shape[1] == self.spec.input_channels[0] and x_fast.shape[1] == self.spec.input_channels[1]
+        pl = self._plan_for(x_slow, x_fast, slow_t_index, train)
+        if train:
+            self.drop_seed.add_(1)
+        self._run(pl.fwd, self._stream())
+        return pl
+
+    def backward(self, pl: Plan, dlogits: Optional[torch.Tensor] = None, zero_grad: bool = True):
+        """Fills the gradient arena self.G from pl.dlogits (or the given dlogits)."""
+        if dlogits is not None:
+            pl.dlogits.copy_(dlogits)
+        if zero_grad:
+            self.G.zero_()
+        self._run(pl.bwd, self._stream())
+
+    # ---- fused loss + optimiser (train.py:228-231 without the per-step .item() sync of :236)
+    def loss_ops(self, pl: Plan, labels: torch.Tensor, loss_out, loss_sum, correct, gscale: float = 1.0) -> Run:
+        n, k = pl.logits.shape
+        return self.be.softmax_ce(pl.logits, labels, n, k, gscale, pl.dlogits, loss_out, loss_sum, correct)
+
+    def adam_ops(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> Run:
+        if self.adam_m is None:
+            self.adam_m = self._new(self.arena_numel)
+            self.adam_v = self._new(self.arena_numel)
+            self.adam_step = self._new(1, dtype=torch.int64)
+        return self.be.adam(self.P.data, self.G, self.adam_m, self.adam_v, self.arena_numel, lr, betas[0], betas[1],
+                            eps, grad_scale, self.adam_step, None)
