@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Benchmark of BASELINE.json's metric: clips/sec of a full training step (forward, cross-entropy, backward,
+gradient all-reduce, Adam) of SlowFast-R50 8x8 on synthetic 3 x 32 x 224^2 bf16 clips, 32 clips per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment); weak scaling (32 clips per GPU); inputs
+are resident in HBM before the timed region; rank 0 prints ONE JSON line.  Besides the contract keys the line holds
+  roofline      the dominant kernel (by device time in one step): algorithmic FLOPs / summed launch durations, both
+                measured live with HIP events on the launch stream in a separate, untimed, instrumented step
+  stages        the same accounting for every kernel class (MFMA TFLOP/s for convs, HBM GB/s for BN / pool stages)
+  cpu_baseline  the oracle (torch.nn restatement of the reference path) running the same training step on the host
+                cores, on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md (vendor figure without sparsity)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 achievable (same guide)
+MFMA_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+
+
+def instrumented_step(step, pl, frames, labels, idx):
+    """One eager step with a HIP event pair around every kernel of the schedule (same stream the kernels launch on).
+    Returns {kind: {'ms', 'flops', 'bytes', 'launches'}}."""
+    eng = step.eng
+    st = eng._stream()
+    ops = step._build(pl, labels)
+    ev = []
+
+    def timed(oplist):
+        for op, meta in zip(oplist, oplist.meta):
+            if meta is None:
+                op(st)
+                continue
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            op(st)
+            b.record()
+            ev.append((meta, a, b))
+
+    eng.drop_seed.add_(1)
+    timed(pl.fwd)
+    ops["zero_loss"](st); ops["loss"](st); ops["zero_grad"](st)
+    timed(pl.bwd)
+    ops["adam"](st)
+    torch.cuda.synchronize()
+    out = {}
+    for meta, a, b in ev:
+        kind = meta["kind"]
+        if kind in ("conv_fwd", "conv_dgrad"):
+            kind = "conv_igemm"
+        d = out.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        d["ms"] += a.elapsed_time(b)
+        d["flops"] += meta.get("flops", 0.0)
+        d["bytes"] += meta.get("bytes", 0.0)
+        d["launches"] += 1
+    return out
+
+
+def cpu_baseline(budget_s: float = 20.0):
+    """The oracle's training step (forward, CE, backward, Adam; reference train.py:225-231) at the metric geometry,
+    fp32, on the host cores.  Bounded sample: 1 clip per step, one warm-up step, then steps until ~budget_s."""
+    from oracle import my_slowfast as o
+    torch.manual_seed(1234)
+    model = o.canonical_slowfast_8x8(400)
+    optim = torch.optim.Adam(model.parameters(), lr=2e-4)
+    frames = torch.randn(1, 3, 32, 224, 224)
+    labels = torch.randint(0, 400, (1,))
+    x = o.pack_pathway(frames)
+    t0 = time.time()
+    o.train_step(model, optim, x, labels)
+    warm = time.time() - t0
+    nsteps = max(1, min(4, int(budget_s / max(warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(nsteps):
+        o.train_step(model, optim, x, labels)
+    dt = time.time() - t0
+    return {"value": round(nsteps / dt, 4), "unit": "clips/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsteps} training step(s) of 1 clip (3x32x224^2, fp32) after 1 warm-up step; "
+                      f"torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--classes", type=int, default=400)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from video_classification_amd import dist as sdist
+    from video_classification_amd.slowfast import pack_pathway_index, slowfast_r50_8x8
+    from video_classification_amd.train import TrainStep
+
+    rank, world, local = sdist.init_process_group_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = slowfast_r50_8x8(args.classes, dtype=torch.bfloat16, device=dev, seed=0)
+    model.train()
+    eng = model.engine
+    gen = torch.Generator().manual_seed(1234 + rank)
+    B = args.batch
+    frames = torch.randn(B, 3, 32, 224, 224, generator=gen).to(torch.bfloat16).to(dev)   # N,C,T,H,W resident in HBM
+    labels = torch.randint(0, args.classes, (B,), generator=gen).to(dev)
+    idx = pack_pathway_index(32, 4, dev)                   # slow pathway = frames [0,4,8,13,17,22,26,31]
+    reducer = sdist.GradReducer(eng.G, bucket_mb=32.0) if world > 1 else None
+    step = TrainStep(eng, lr=2e-4, use_graph=not args.no_graph, reducer=reducer)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2 if step.use_graph else 0)):
+        step(frames, frames, labels, slow_t_index=idx)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(frames, frames, labels, slow_t_index=idx)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    final_loss = float(step.loss[0])
+
+    line = {
+        "metric": "clips/sec SlowFast-R50 8x8, 32x224^2 bf16 training step", "value": round(args.steps * B * world / dt, 2),
+        "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "config/slowfast-Torso.yaml path at the metric geometry: SlowFast-R50 8x8, "
+                               "3x32x224^2 clips, fwd+CE+bwd+Adam", "clips_per_gpu": B, "global_batch": B * world,
+                   "classes": args.classes, "parallelism": f"dp{world}", "hipgraph": bool(step.use_graph),
+                   "params": eng.num_parameters()},
+        "loss_after": round(final_loss, 4),
+    }
+    if rank == 0 and not args.no_roofline:
+        pl = eng._plan_for(frames, frames, idx, True)
+        stages = instrumented_step(step, pl, frames, labels, idx)
+        rep = {}
+        for kind, d in stages.items():
+            sec = d["ms"] * 1e-3
+            r = {"ms_per_step": round(d["ms"], 3), "launches": d["launches"]}
+            if d["flops"] > 0:
+                r["tflops"] = round(d["flops"] / sec / 1e12, 1)
+            if d["bytes"] > 0:
+                r["algorithmic_GBps"] = round(d["bytes"] / sec / 1e9, 1)
+            rep[kind] = r
+        line["stages"] = rep
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        d = stages[dom]
+        sec = d["ms"] * 1e-3
+        if d["flops"] > 0:
+            ach = d["flops"] / sec / 1e12
+            line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_BF16_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
+                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"]}
+        else:
+            ach = d["bytes"] / sec / 1e9
+            line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                                "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,329 @@
+"""GPU parity, kernel by kernel, THROUGH THE C ABI: every libsfk entry point against the torch-CPU restatement of
+its contract (tests/emu_backend.py, itself pinned to torch's conv3d / autograd in test_plan_cpu.py) on identical
+seeded inputs.  fp32 results must agree to fp32 rounding; bf16 feature maps to one bf16 ulp (2^-8 relative),
+with their fp32 side outputs (BN partial sums, filter gradients) held to fp32 accuracy."""
+import pytest
+import torch
+
+from emu_backend import EmuBackend
+from helpers import rel_err
+from video_classification_amd._lib import ConvPass, FMap, Im2col, WgradPass
+from video_classification_amd.plan import ConvGeom, dgrad_passes, fwd_pass, wgrad_taps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 8e-3}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from video_classification_amd._lib import HipBackend
+    return HipBackend()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def mk(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+def fmap_pair(n, c, t, h, w, dtype, gen, ld=None, c_off=0, fill=None):
+    """Identical feature maps on CPU and GPU (optionally a channel slice of a wider record)."""
+    ld = c if ld is None else ld
+    if fill is None:
+        buf = mk((n * t * h * w * ld,), dtype, gen)
+    else:
+        buf = torch.full((n * t * h * w * ld,), fill, dtype=dtype)
+    return FMap(buf, n, t, h, w, c, ld, c_off), FMap(buf.to(DEV), n, t, h, w, c, ld, c_off)
+
+
+CONV_CASES = [
+    # cin, cout, k, s, p, (n, t, h, w)                      what it exercises
+    (8, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 5, 9, 7)),       # BN=16 tile, half-empty co fragment, ragged M
+    (16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 3, 10, 11)),   # BN=16, 9 taps, cin < BK
+    (32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 12, 14)),   # BN=32, stride-2
+    (80, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 9, 9)),     # BN=64, cin = 2.5 K-steps (slow res2 conv_a)
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 7, 7)),    # BN=128, 2 co tiles, M = 196
+    (320, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 2, 8, 8)),   # strided shortcut, 10 K-steps
+    (128, 136, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 5, 6)),   # cout not a multiple of 16 / of the tile
+    (8, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (2, 16, 6, 5)),     # canonical lateral fusion
+    (160, 8, (5, 1, 1), (1, 1, 1), (2, 0, 0), (1, 8, 6, 6)),     # fast stem temporal part over the patch matrix
+    (8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1, 1)),       # a single pixel
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in CONV_CASES])
+def test_conv_forward_and_stats(hip, dtype, case):
+    cin, cout, k, s, p, (n, t, h, w) = case
+    gen = torch.Generator().manual_seed(hash(case) % 1000)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, k, s, p)
+    sp = fwd_pass(g, (t, h, w))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    yc, yg = fmap_pair(n, cout, *sp.rows, dtype, gen, ld=cout + 4, c_off=4, fill=3.0)
+    wt = mk((cout * g.wtaps * cin,), dtype, gen, scale=(g.wtaps * cin) ** -0.5)
+    pc = ConvPass(xc, yc, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, g.wtaps, cin, cout)
+    pg = ConvPass(xg, yg, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(DEV), g.wtaps, cin, cout)
+    mt = hip.conv_igemm_mtiles(pg)
+    assert mt == emu.conv_igemm_mtiles(pc)
+    pc.stats = torch.zeros(mt * cout * 2)
+    pg.stats = torch.full((mt * cout * 2,), float("nan"), device=DEV)
+    emu.conv_igemm(pc)(0)
+    hip.conv_igemm(pg)(stream())
+    torch.cuda.synchronize()
+    assert rel_err(yg.view5().float().cpu(), yc.view5().float()) < TOL[dtype]
+    wide = yg.buf.cpu().float().view(-1, cout + 4)
+    assert torch.all(wide[:, :4] == 3.0)                            # the neighbouring channel slice is untouched
+    sg, sc = pg.stats.cpu().view(mt, cout, 2), pc.stats.view(mt, cout, 2)
+    assert torch.isfinite(sg).all()
+    assert rel_err(sg.sum(0), sc.sum(0)) < 1e-4                     # fp32 partial sums even in bf16 mode
+    assert rel_err(sg, sc) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES[:9], ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in CONV_CASES[:9]])
+def test_conv_data_gradient(hip, dtype, case):
+    cin, cout, k, s, p, (n, t, h, w) = case
+    gen = torch.Generator().manual_seed(7 + hash(case) % 1000)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, k, s, p)
+    od = g.out_dims((t, h, w))
+    passes, needs_zero = dgrad_passes(g, (t, h, w))
+    dyc, dyg = fmap_pair(n, cout, *od, dtype, gen)
+    wt = mk((cin * g.wtaps * cout,), dtype, gen, scale=(g.wtaps * cout) ** -0.5)     # [ci][tap][co]
+    for accumulate in (False, True):
+        dxc, dxg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=0)
+        if not accumulate:
+            dxc.view5().zero_(); dxg.view5().zero_()
+        for sp_ in passes:
+            emu.conv_igemm(ConvPass(dyc, dxc, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wt, g.wtaps, cout,
+                                    cin, accumulate=accumulate))(0)
+            hip.conv_igemm(ConvPass(dyg, dxg, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wt.to(DEV), g.wtaps,
+                                    cout, cin, accumulate=accumulate))(stream())
+        torch.cuda.synchronize()
+        assert rel_err(dxg.view5().float().cpu(), dxc.view5().float()) < TOL[dtype]
+        assert torch.equal(dxg.buf.cpu().float().view(-1, cin + 8)[:, cin:], dxc.buf.float().view(-1, cin + 8)[:, cin:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in CONV_CASES])
+def test_conv_filter_gradient(hip, dtype, case):
+    cin, cout, k, s, p, (n, t, h, w) = case
+    gen = torch.Generator().manual_seed(11 + hash(case) % 1000)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, k, s, p)
+    od = g.out_dims((t, h, w))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    dyc, dyg = fmap_pair(n, cout, *od, dtype, gen, ld=cout + 8, c_off=0)
+    base = torch.randn(cout * g.wtaps * cin, generator=gen)        # dW is accumulated INTO
+    dwc, dwg = base.clone(), base.clone().to(DEV)
+    emu.conv_wgrad(WgradPass(xc, dyc, g.s, list(wgrad_taps(g)), dwc, g.wtaps, cin, cout))(0)
+    hip.conv_wgrad(WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), dwg, g.wtaps, cin, cout))(stream())
+    torch.cuda.synchronize()
+    assert rel_err(dwg.cpu(), dwc) < 5e-5                            # fp32 atomics: order differs, accuracy does not
+
+
+def test_conv_rejects_bad_descriptors(hip):
+    from video_classification_amd._lib import SfkError
+    gen = torch.Generator().manual_seed(0)
+    _, x = fmap_pair(1, 8, 1, 4, 4, torch.bfloat16, gen)
+    _, y = fmap_pair(1, 8, 1, 4, 4, torch.bfloat16, gen)
+    w = torch.zeros(64, dtype=torch.bfloat16, device=DEV)
+    bad_cin = ConvPass(x, y, (1, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0), [(0, 0, 0, 0)], w, 1, 16, 8)
+    with pytest.raises(SfkError):
+        hip.conv_igemm(bad_cin)(stream())
+    oob = ConvPass(x, y, (1, 4, 4), (1, 1, 1), (2, 2, 2), (0, 0, 0), [(0, 0, 0, 0)], w, 1, 8, 8)   # scatter leaves y
+    with pytest.raises(SfkError):
+        hip.conv_igemm(oob)(stream())
+    _, x6 = fmap_pair(1, 6, 1, 4, 4, torch.bfloat16, gen)                                           # cin % 8 != 0
+    with pytest.raises(SfkError):
+        hip.conv_igemm(ConvPass(x6, y, (1, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0), [(0, 0, 0, 0)], w, 1, 6, 8))(stream())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("src_dtype", DTYPES, ids=["src_f32", "src_bf16"])
+def test_stem_im2col(hip, dtype, src_dtype):
+    gen = torch.Generator().manual_seed(3)
+    emu = EmuBackend()
+    clips = mk((2, 6, 21, 18, 22), src_dtype, gen)                  # dataset memory N,T,C,H,W
+    for chan, t_index in (((0, 5), None), ((5, 20), None), ((0, 3), torch.tensor([0, 2, 5], dtype=torch.int32))):
+        view = clips.permute(0, 2, 1, 3, 4)[:, chan[0]:chan[1]]     # NCTHW view, nothing copied (train.py:136-140)
+        cin = chan[1] - chan[0]
+        t_out = 6 if t_index is None else 3
+        kpad = (49 * cin + 7) // 8 * 8
+        oc, og = fmap_pair(2, kpad, t_out, 9, 11, dtype, gen, fill=5.0)
+        emu.stem_im2col(Im2col(view, t_index, 7, 7, (2, 2), (3, 3), oc))(0)
+        vg = clips.to(DEV).permute(0, 2, 1, 3, 4)[:, chan[0]:chan[1]]
+        hip.stem_im2col(Im2col(vg, None if t_index is None else t_index.to(DEV), 7, 7, (2, 2), (3, 3), og))(stream())
+        torch.cuda.synchronize()
+        assert torch.equal(og.view5().float().cpu(), oc.view5().float())      # a pure gather (+ one rounding): bit-exact
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("c", [8, 64, 80, 2048], ids=lambda c: f"c{c}")
+def test_batchnorm_forward_backward(hip, dtype, c):
+    gen = torch.Generator().manual_seed(c)
+    emu = EmuBackend()
+    n, t, h, w = (2, 3, 5, 7) if c < 2048 else (2, 2, 3, 3)
+    px = n * t * h * w
+    yc, yg = fmap_pair(n, c, t, h, w, dtype, gen, ld=c + 8, c_off=8)
+    rc, rg = fmap_pair(n, c, t, h, w, dtype, gen)
+    gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.3
+
+    def side(be, y, res, dev, st):
+        f = lambda *s, **k: torch.zeros(*s, device=dev, **k)
+        parts = f(2048 * c * 2)
+        run, npart = be.bn_stats(y, parts, 2048)
+        run(st)
+        rm, rv, nbt = f(c), torch.ones(c, device=dev), f(1, dtype=torch.int64)
+        mean, invstd, scale, shift = f(c), f(c), f(c), f(c)
+        be.bn_finalize(parts, npart, c, px, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv, nbt, mean, invstd, scale, shift)(st)
+        out = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
+        be.bn_apply(y, scale, shift, res, None, None, True, out)(st)
+        out2 = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
+        be.bn_apply(y, scale, shift, res, scale, shift, False, out2)(st)
+        # backward of out = relu(bn(y) + res): mask from the activation, dz written in place
+        da = FMap(mk((px * c,), dtype, torch.Generator().manual_seed(5)).to(dev), n, t, h, w, c)
+        bparts = f(2048 * c * 2)
+        run, nb = be.bn_bwd_reduce(da, y, out, mean, invstd, scale, shift, True, da, bparts, 2048)
+        run(st)
+        dgamma, dbeta, coef = f(c), f(c), f(c * 3)
+        be.bn_bwd_finalize(bparts, nb, c, px, gamma.to(dev), invstd, dgamma, dbeta, coef)(st)
+        dy = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
+        be.bn_bwd_apply(da, y, None, mean, invstd, scale, shift, False, coef, dy)(st)
+        # backward of relu(bn(y)) with the mask recomputed from y
+        da2 = FMap(mk((px * c,), dtype, torch.Generator().manual_seed(6)).to(dev), n, t, h, w, c)
+        run, nb2 = be.bn_bwd_reduce(da2, y, None, mean, invstd, scale, shift, True, None, bparts, 2048)
+        run(st)
+        coef2 = f(c * 3)
+        be.bn_bwd_finalize(bparts, nb2, c, px, gamma.to(dev), invstd, None, None, coef2)(st)
+        be.bn_bwd_apply(da2, y, None, mean, invstd, scale, shift, True, coef2, da2)(st)   # in place
+        ev_s, ev_h = f(c), f(c)
+        be.bn_eval_coeffs(gamma.to(dev), beta.to(dev), rm, rv, 1e-5, c, ev_s, ev_h)(st)
+        return dict(mean=mean, invstd=invstd, scale=scale, shift=shift, rm=rm, rv=rv, out=out.buf, out2=out2.buf,
+                    dz=da.buf, dgamma=dgamma, dbeta=dbeta, dy=dy.buf, dy2=da2.buf, ev_s=ev_s, ev_h=ev_h,
+                    nbt=nbt.float())
+
+    a = side(emu, yc, rc, "cpu", 0)
+    b = side(hip, yg, rg, DEV, stream())
+    torch.cuda.synchronize()
+    for kname in a:
+        tol = TOL[dtype] if kname in ("out", "out2", "dz", "dy", "dy2") else 2e-4
+        assert rel_err(b[kname].float().cpu(), a[kname].float()) < tol, kname
+    # and against torch's own BatchNorm for the statistics
+    v = yc.view5().float().reshape(-1, c)
+    assert rel_err(b["mean"].cpu(), v.mean(0)) < 1e-5
+    assert rel_err(b["rv"].cpu(), 0.9 + 0.1 * v.var(0, unbiased=True)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_maxpool_with_ties(hip, dtype):
+    gen = torch.Generator().manual_seed(2)
+    emu = EmuBackend()
+    for (h, w) in ((12, 14), (7, 9)):
+        xc, xg = fmap_pair(2, 16, 3, h, w, dtype, gen)
+        xc.view5().clamp_(min=0); xg.view5().clamp_(min=0)          # post-ReLU: many exact ties at 0
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        yc, yg = fmap_pair(2, 16, 3, ho, wo, dtype, gen, ld=24, c_off=8)
+        ac = torch.zeros(yc.pixels * 16, dtype=torch.uint8)
+        ag = torch.zeros(yc.pixels * 16, dtype=torch.uint8, device=DEV)
+        emu.maxpool_fwd(xc, yc, ac, 3, 2, 1)(0)
+        hip.maxpool_fwd(xg, yg, ag, 3, 2, 1)(stream())
+        torch.cuda.synchronize()
+        assert torch.equal(yg.view5().float().cpu(), yc.view5().float())
+        assert torch.equal(ag.cpu(), ac)
+        # torch's own pool agrees on values and on which element wins a tie
+        ref, idx = torch.nn.functional.max_pool3d(xc.view5().float().permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2),
+                                                  (0, 1, 1), return_indices=True)
+        assert torch.equal(ref.permute(0, 2, 3, 4, 1), yc.view5().float())
+        dyc, dyg = fmap_pair(2, 16, 3, ho, wo, dtype, gen)
+        dxc, dxg = fmap_pair(2, 16, 3, h, w, dtype, gen)
+        emu.maxpool_bwd(dyc, ac, dxc, 3, 2, 1)(0)
+        hip.maxpool_bwd(dyg, ag, dxg, 3, 2, 1)(stream())
+        torch.cuda.synchronize()
+        assert rel_err(dxg.view5().float().cpu(), dxc.view5().float()) < TOL[dtype]
+        xt = xc.view5().float().permute(0, 4, 1, 2, 3).requires_grad_(True)
+        torch.nn.functional.max_pool3d(xt, (1, 3, 3), (1, 2, 2), (0, 1, 1)).backward(dyc.view5().float().permute(0, 4, 1, 2, 3))
+        assert rel_err(dxc.view5().float(), xt.grad.permute(0, 2, 3, 4, 1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [((4, 2, 2), (6, 4, 4)), ((8, 7, 7), (8, 7, 7)), ((1, 1, 1), (2, 2, 2))], ids=["ref", "global", "unit"])
+def test_head_pool_dropout_fc_loss(hip, dtype, geom):
+    k, (t, h, w) = geom
+    gen = torch.Generator().manual_seed(4)
+    emu = EmuBackend()
+    n, c, F, K = 3, 24, 40, 11
+    xc, xg = fmap_pair(n, c, t, h, w, dtype, gen)
+    P = (t - k[0] + 1) * (h - k[1] + 1) * (w - k[2] + 1)
+    seed = torch.tensor([1234567], dtype=torch.int64)
+    wfc, bfc = torch.randn(K * F, generator=gen) * 0.2, torch.randn(K, generator=gen)
+    labels = torch.tensor([3, 0, 10])
+    for rate in (0.0, 0.5):
+        def side(be, x, dev, st):
+            f = lambda *s, **kw: torch.zeros(*s, device=dev, **kw)
+            feat = torch.full((n * F,), 0.25, device=dev)
+            be.head_pool_fwd(x, k, rate, seed.to(dev), feat, F, 8)(st)
+            mask = f(n * c * P, dtype=torch.uint8)
+            be.head_dropout_mask(n, c, 8, P, rate, seed.to(dev), mask)(st)
+            logits = f(n, K)
+            be.fc_fwd(feat, wfc.to(dev), bfc.to(dev), logits, n, F, K)(st)
+            dl, loss, lsum, corr = f(n, K), f(1), f(1), f(1, dtype=torch.int32)
+            be.softmax_ce(logits, labels.to(dev), n, K, 1.0, dl, loss, lsum, corr)(st)
+            dfeat, dw, db = f(n * F), f(K * F), f(K)
+            be.fc_bwd(dl, feat, wfc.to(dev), dfeat, dw, db, n, F, K)(st)
+            dx = FMap(torch.zeros(x.pixels * c, dtype=dtype, device=dev), n, t, h, w, c)
+            be.head_pool_bwd(dfeat, F, 8, k, rate, seed.to(dev), dx)(st)
+            return dict(feat=feat, mask=mask.float(), logits=logits, dl=dl, loss=loss, corr=corr.float(), dfeat=dfeat,
+                        dw=dw, db=db, dx=dx.buf)
+        a = side(emu, xc, "cpu", 0)
+        b = side(hip, xg, DEV, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(b["mask"].cpu(), a["mask"])              # the counter-based mask is reproducible bit for bit
+        if rate > 0:
+            assert 0.35 < float(a["mask"].mean()) < 0.65
+        for kname in a:
+            tol = TOL[dtype] if kname == "dx" else 1e-4
+            assert rel_err(b[kname].float().cpu(), a[kname].float()) < tol, (kname, rate)
+        # the loss against torch
+        want = torch.nn.functional.cross_entropy(a["logits"], labels)
+        assert abs(float(b["loss"][0]) - float(want)) < 1e-5
+
+
+def test_adam_matches_torch(hip):
+    gen = torch.Generator().manual_seed(8)
+    count = 10_007
+    p0 = torch.randn(count + 1, generator=gen)[:count + 1]
+    p_t = torch.nn.Parameter(p0[:count].clone())
+    opt = torch.optim.Adam([p_t], lr=2e-4)
+    pg = torch.zeros(10_016, device=DEV); pg[:count] = p0[:count].to(DEV)
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for it in range(5):
+        g = torch.randn(count, generator=gen)
+        p_t.grad = g.clone()
+        opt.step()
+        gg = torch.zeros_like(pg); gg[:count] = g.to(DEV)
+        hip.adam(pg, gg, m, v, count, 2e-4, 0.9, 0.999, 1e-8, 1.0, step, None)(stream())
+    torch.cuda.synchronize()
+    assert int(step[0]) == 5
+    assert rel_err(pg[:count].cpu(), p_t.detach()) < 1e-6
+    assert float(pg[count:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_filter_transpose_and_cast(hip, dtype):
+    gen = torch.Generator().manual_seed(9)
+    cout, taps, cin = 24, 3, 40
+    src = torch.randn(cout * taps * cin, generator=gen)
+    dst = torch.zeros(cout * taps * cin, dtype=dtype, device=DEV)
+    hip.filter_transpose(src.to(DEV), dst, cout, taps, cin)(stream())
+    sh = torch.zeros(src.numel(), dtype=dtype, device=DEV)
+    hip.cast(src.to(DEV), sh, src.numel())(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu().view(cin, taps, cout), src.view(cout, taps, cin).permute(2, 1, 0).to(dtype))
+    assert torch.equal(sh.cpu(), src.to(dtype))

@@ -58,13 +58,43 @@ class _UnitRec:
     shift: torch.Tensor
 
 
+class OpList(list):
+    """A kernel schedule; `meta[i]` describes op i for the profiler / roofline report (None for glue ops)."""
+
+    def __init__(self):
+        super().__init__()
+        self.meta: List[Optional[dict]] = []
+
+    def append(self, op, **meta):
+        super().append(op)
+        self.meta.append(meta or None)
+
+
 class Plan:
     def __init__(self):
-        self.fwd: List[Run] = []
-        self.bwd: List[Run] = []
+        self.fwd: OpList = OpList()
+        self.bwd: OpList = OpList()
         self.logits: torch.Tensor = None
         self.dlogits: torch.Tensor = None
         self.key = None
+        # (index one past the backward op that finishes it, (arena offset, numel)): every gradient range has ONE writer
+        self.grad_marks: List[Tuple[int, Tuple[int, int]]] = []
+        self.im2col_slots: List[Tuple[int, int]] = []     # (index in fwd, pathway) of the ops bound to the input tensors
+
+    def grad_segments(self, nseg: int) -> List[Tuple[int, int, List[Tuple[int, int]]]]:
+        """Cut the backward schedule into nseg pieces [(op_begin, op_end, finished gradient ranges)], balanced by
+        gradient bytes, for overlapping the all-reduce with the rest of backward."""
+        total = sum(r[1] for _, r in self.grad_marks)
+        marks = sorted(self.grad_marks)
+        segs, begin, acc, cur, k = [], 0, 0, [], 1
+        for end, rng in marks:
+            cur.append(rng)
+            acc += rng[1]
+            if acc >= total * k / nseg and k < nseg:
+                segs.append((begin, end, cur))
+                begin, cur, k = end, [], k + 1
+        segs.append((begin, len(self.bwd), cur))
+        return segs
 
 
 class Engine:
@@ -283,7 +313,11 @@ class Engine:
             mt = self.be.conv_igemm_mtiles(p)
             stats = self._buf(stats_tag, mt * L.c * 2, torch.float32)
             p.stats = stats
-        pl.fwd.append(self.be.conv_igemm(p))
+        rows = x.n * sp.rows[0] * sp.rows[1] * sp.rows[2]
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        pl.fwd.append(self.be.conv_igemm(p), kind="conv_fwd", layer=L.cb.conv_key, cout=L.eg.cout,
+                      flops=2.0 * rows * L.eg.cout * L.eg.cin * L.eg.wtaps,
+                      bytes=float(esz * (x.pixels * L.eg.cin + rows * L.eg.cout + L.w_numel)))
         return stats, mt
 
     def _unit_fwd(self, pl: Plan, L: _Layer, x: FMap, tag: str, train: bool, n: int):
@@ -306,6 +340,11 @@ class Engine:
             pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, L.rm, L.rv, self.spec.bn_eps, L.c, scale, shift))
         return y, scale, shift, rec
 
+    def _apply(self, pl: Plan, y: FMap, scale, shift, res, res_scale, res_shift, relu: bool, out: FMap):
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        pl.fwd.append(self.be.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out), kind="bn_apply",
+                      bytes=float(y.pixels * y.c * esz * (2 + (1 if res is not None else 0))))
+
     def _bn_bwd(self, pl: Plan, rec: _UnitRec, da: FMap, tag: str, relu: bool, mask_src: Optional[FMap],
                 dz_inplace: bool, dy: FMap):
         """BatchNorm(+ReLU) backward of one unit: da -> dy (may alias da), accumulates dgamma/dbeta."""
@@ -314,20 +353,30 @@ class Engine:
         coef = self._buf(f"coef.{tag}", L.c * 3, torch.float32)
         run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
                                          da if dz_inplace else None, parts, MAX_PARTS)
-        pl.bwd.append(run)
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        el = float(rec.y.pixels * L.c * esz)
+        pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
+                      bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0)))
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                               self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef))
+        pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
         if dz_inplace:   # the mask is already applied to da
             pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False,
-                                               coef, dy))
+                                               coef, dy), kind="bn_bwd_apply", layer=L.cb.norm_key, bytes=el * 3)
         else:
             pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
-                                               coef, dy))
+                                               coef, dy), kind="bn_bwd_apply", layer=L.cb.norm_key,
+                          bytes=el * (3 + (1 if mask_src is not None else 0)))
 
     def _wgrad(self, pl: Plan, rec: _UnitRec, dy: FMap):
         L = rec.L
+        esz = 2 if self.dtype == torch.bfloat16 else 4
         pl.bwd.append(self.be.conv_wgrad(WgradPass(rec.x, dy, L.eg.s, list(wgrad_taps(L.eg)),
-                                                   self._gslice(L.w_off, L.w_numel), L.eg.wtaps, L.eg.cin, L.eg.cout)))
+                                                   self._gslice(L.w_off, L.w_numel), L.eg.wtaps, L.eg.cin, L.eg.cout)),
+                      kind="conv_wgrad", layer=L.cb.conv_key, cout=L.eg.cout,
+                      flops=2.0 * dy.pixels * L.eg.cout * L.eg.cin * L.eg.wtaps,
+                      bytes=float(esz * (rec.x.pixels * L.eg.cin + dy.pixels * L.eg.cout) + 4 * L.w_numel))
+        pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
 
     def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool):
         """data gradient of rec's conv: dy -> dx (+= when accumulate)."""
@@ -338,9 +387,15 @@ class Engine:
             assert dx.ld == dx.c and dx.c_off == 0, "zero-fill of a channel slice is not supported"
             pl.bwd.append(self.be.fill_zero(dx.buf[: dx.pixels * dx.ld]))
         wt = self.St[L.w_off:L.w_off + L.w_numel]
+        esz = 2 if self.dtype == torch.bfloat16 else 4
         for sp in passes:
+            rows = dy.n * sp.rows[0] * sp.rows[1] * sp.rows[2]
             pl.bwd.append(self.be.conv_igemm(ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt,
-                                                      L.eg.wtaps, L.eg.cout, L.eg.cin, accumulate=accumulate)))
+                                                      L.eg.wtaps, L.eg.cout, L.eg.cin, accumulate=accumulate)),
+                          kind="conv_dgrad", layer=L.cb.conv_key, cout=L.eg.cin,
+                          flops=2.0 * rows * L.eg.cout * L.eg.cin * len(sp.taps),
+                          bytes=float(esz * (dy.pixels * L.eg.cout / len(passes) + rows * L.eg.cin * (2 if accumulate else 1)
+                                             + L.w_numel)))
 
     # ---- stem: im2col -> temporal conv -> BN -> ReLU -> MaxPool
     def _stem_fwd(self, pl, p: int, x5: torch.Tensor, t_index, out: FMap, train: bool):
@@ -351,10 +406,11 @@ class Engine:
         ho = (h_in + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
         wo = (w_in + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
         cols = self._fmap(f"cols.{p}", n, t_out, ho, wo, L.eg.cin)
+        pl.im2col_slots.append((len(pl.fwd), p))
         pl.fwd.append(self.be.stem_im2col(Im2col(x5, t_index, g.k[1], g.k[2], (g.s[1], g.s[2]), (g.p[1], g.p[2]), cols)))
         y, scale, shift, rec = self._unit_fwd(pl, L, cols, f"stem{p}", train, n)
         a = self._fmap(f"a.stem{p}", n, y.t, y.h, y.w, L.c)
-        pl.fwd.append(self.be.bn_apply(y, scale, shift, None, None, None, True, a))
+        self._apply(pl, y, scale, shift, None, None, None, True, a)
         assert (out.h, out.w) == ((a.h + 2 - 3) // 2 + 1, (a.w + 2 - 3) // 2 + 1) and out.t == a.t
         argmax = self._buf(f"argmax.{p}", out.pixels * L.c, torch.uint8)
         pl.fwd.append(self.be.maxpool_fwd(a, out, argmax, 3, 2, 1))
@@ -373,7 +429,7 @@ class Engine:
         y, scale, shift, rec = self._unit_fwd(pl, L, xf, f"fuse{bi}", train, xf.n)
         assert (y.t, y.h, y.w, y.c) == (out_slice.t, out_slice.h, out_slice.w, out_slice.c), \
             "lateral fusion: fast pathway does not line up with the slow pathway (T_fast / stride != T_slow?)"
-        pl.fwd.append(self.be.bn_apply(y, scale, shift, None, None, None, True, out_slice))
+        self._apply(pl, y, scale, shift, None, None, None, True, out_slice)
         return rec
 
     def _fusion_bwd(self, pl, bi: int, rec: _UnitRec, d_slice: FMap, d_xf: FMap):
@@ -393,16 +449,16 @@ class Engine:
             y1, s1, h1, rec1 = self._unit_fwd(pl, L1, x, f"{tag}.b1", train, n)
         ya, sa, ha, reca = self._unit_fwd(pl, La, x, f"{tag}.a", train, n)
         aa = self._fmap(f"a.{tag}.a", n, ya.t, ya.h, ya.w, La.c)
-        pl.fwd.append(self.be.bn_apply(ya, sa, ha, None, None, None, True, aa))
+        self._apply(pl, ya, sa, ha, None, None, None, True, aa)
         yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n)
         ab = self._fmap(f"a.{tag}.b", n, yb.t, yb.h, yb.w, Lb.c)
-        pl.fwd.append(self.be.bn_apply(yb, sb, hb, None, None, None, True, ab))
+        self._apply(pl, yb, sb, hb, None, None, None, True, ab)
         yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n)
         assert (yc.t, yc.h, yc.w, yc.c) == (out.t, out.h, out.w, out.c)
         if blk.branch1 is not None:
-            pl.fwd.append(self.be.bn_apply(yc, sc, hc, y1, s1, h1, True, out))
+            self._apply(pl, yc, sc, hc, y1, s1, h1, True, out)
         else:
-            pl.fwd.append(self.be.bn_apply(yc, sc, hc, x, None, None, True, out))
+            self._apply(pl, yc, sc, hc, x, None, None, True, out)
         return (blk, tag, x, out, rec1, reca, recb, recc)
 
     def _block_bwd(self, pl, brec, d_out: FMap) -> FMap:
@@ -525,6 +581,7 @@ class Engine:
         dfeat = self._buf("dfeat", n * F, torch.float32)
         pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, self._gslice(self.fc_w_off, F * K),
                                 self._gslice(self.fc_b_off, K), n, F, K))
+        pl.grad_marks.append((len(pl.bwd), (self.fc_w_off, self.layers[0].g_off - self.fc_w_off)))
         d_xs = self._fmap("d.cat.4", n, xs_out.t, xs_out.h, xs_out.w, xs_out.c)
         d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
         pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
@@ -549,17 +606,39 @@ class Engine:
 
     # ------------------------------------------------------------------ execution
     def _plan_for(self, x_slow, x_fast, slow_t_index, train: bool) -> Plan:
-        def sig(t):
-            return None if t is None else (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
-        key = (sig(x_slow), sig(x_fast), sig(slow_t_index), train)
+        """Plans are keyed on geometry (shapes, strides, dtypes); only the two im2col ops hold the input
+        addresses, so a new batch tensor re-binds those two ops instead of rebuilding ~1000 descriptors."""
+        def geo(t):
+            return None if t is None else (tuple(t.shape), tuple(t.stride()), t.dtype)
+
+        def ptrs():
+            return tuple(None if t is None else t.data_ptr() for t in (x_slow, x_fast, slow_t_index))
+        key = (geo(x_slow), geo(x_fast), geo(slow_t_index), train)
         pl = self._plans.get(key)
         if pl is None:
-            if len(self._plans) > 8:
+            if len(self._plans) >= 6:
                 self._plans.clear()
             pl = self._build_plan(x_slow, x_fast, slow_t_index, train)
             pl.key = key
+            pl.bound = ptrs()
             pl.inputs = (x_slow, x_fast, slow_t_index)   # keep the bound tensors alive
+            pl.graph_epoch = 0
             self._plans[key] = pl
+        elif pl.bound != ptrs():
+            for slot, p in pl.im2col_slots:
+                L = self._layers[self.wiring.stems[p].conv_key]
+                g = L.cb.geom
+                x5 = x_slow if p == 0 else x_fast
+                t_idx = slow_t_index if p == 0 else None
+                t_out = x5.shape[2] if t_idx is None else int(t_idx.numel())
+                ho = (x5.shape[3] + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
+                wo = (x5.shape[4] + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
+                cols = self._fmap(f"cols.{p}", x5.shape[0], t_out, ho, wo, L.eg.cin)
+                pl.fwd[slot] = self.be.stem_im2col(Im2col(x5, t_idx, g.k[1], g.k[2], (g.s[1], g.s[2]),
+                                                          (g.p[1], g.p[2]), cols))
+            pl.bound = ptrs()
+            pl.inputs = (x_slow, x_fast, slow_t_index)
+            pl.graph_epoch += 1                          # a captured hipGraph of this plan is stale now
         return pl
 
     def _stream(self) -> int:

@@ -1,0 +1,315 @@
+"""Training loop with the reference's surface (train.py): ``ModelManager(cfg)``, ``Trainer(cfg)``, ``.train()``,
+``.train_epoch()``, ``.run_eval(loader) -> {'ps','t','acc','sv'}``, ``.save_ckpt/.load_ckpt``.
+
+What differs from /root/reference/train.py, and why:
+  * the step (forward, CrossEntropyLoss, zero_grad, backward, Adam -- train.py:225-231) is ONE flat schedule of
+    libsfk kernels (``TrainStep``), optionally replayed as a hipGraph; loss and accuracy are accumulated on the
+    device, so there is no ``.item()`` sync per step (train.py:236) -- they are read once per epoch;
+  * N>1: one process per GPU; the loaders shard clips over ranks and ``TrainStep`` all-reduces the gradient arena
+    over RCCL while backward is still running (dist.py).  The reference is single-GPU;
+  * datasets are injected (``train_loader`` / ``test_loader``) or built from the reference's own
+    ``ChalearnVideoDataset`` when that module is importable; items keep its contract: a dict
+    {cfg.MODEL.R3D_INPUT: (T,21,S,S) float32, 'label': int} (lists of such dicts for the test set).
+"""
+from __future__ import annotations
+
+import glob
+from pathlib import Path
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+import torch.utils.data
+from torch.utils.data.dataloader import default_collate
+
+from . import dist as sdist
+from .config import crop_resize_dict
+from .engine import Engine
+from .slowfast import init_my_slowfast
+
+
+class TrainStep:
+    """One optimisation step on one rank: forward -> mean cross-entropy -> backward -> (all-reduce) -> Adam."""
+
+    def __init__(self, engine: Engine, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
+                 reducer: Optional[sdist.GradReducer] = None, overlap_segments: int = 6):
+        self.eng, self.lr, self.betas, self.eps = engine, lr, betas, eps
+        self.reducer = reducer
+        self.world = reducer.world if reducer is not None else 1
+        self.use_graph = use_graph and self.world == 1 and engine.device.type == "cuda"
+        self.overlap_segments = overlap_segments
+        dev = engine.device
+        self.loss = torch.zeros(1, device=dev)            # mean loss of the last step
+        self.loss_sum = torch.zeros(1, device=dev)        # running sums since reset_meters()
+        self.correct = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps = 0
+        self._cache = {}
+
+    def reset_meters(self):
+        self.loss_sum.zero_()
+        self.correct.zero_()
+        self.steps = 0
+
+    def _build(self, pl, labels):
+        eng = self.eng
+        ops = dict(
+            loss=eng.loss_ops(pl, labels, self.loss, self.loss_sum, self.correct),
+            adam=eng.adam_ops(self.lr, self.betas, self.eps, 1.0 / self.world),
+            zero_loss=eng.be.fill_zero(self.loss),
+            zero_grad=eng.be.fill_zero(eng.G),
+        )
+        return ops
+
+    def _eager(self, pl, ops):
+        eng = self.eng
+        st = eng._stream()
+        eng.drop_seed.add_(1)
+        eng._run(pl.fwd, st)
+        ops["zero_loss"](st)
+        ops["loss"](st)
+        ops["zero_grad"](st)
+        if self.world == 1:
+            eng._run(pl.bwd, st)
+        else:
+            self.reducer.begin()
+            for a, b, ranges in pl.grad_segments(self.overlap_segments):
+                eng._run(pl.bwd[a:b], st)
+                self.reducer.reduce(ranges)
+            self.reducer.finish()
+        ops["adam"](st)
+
+    def __call__(self, x_slow, x_fast, labels, slow_t_index=None) -> torch.Tensor:
+        eng = self.eng
+        pl = eng._plan_for(x_slow, x_fast, slow_t_index, True)
+        key = (id(pl), labels.data_ptr(), pl.graph_epoch)
+        ent = self._cache.get(key)
+        if ent is None:
+            if len(self._cache) > 4:
+                self._cache.clear()
+            ent = {"ops": self._build(pl, labels), "graph": None, "calls": 0, "labels": labels}
+            self._cache[key] = ent
+        ent["calls"] += 1
+        if not self.use_graph:
+            self._eager(pl, ent["ops"])
+        elif ent["graph"] is not None:
+            ent["graph"].replay()
+        elif ent["calls"] < 2:
+            self._eager(pl, ent["ops"])      # first call: eager (loads code objects, settles allocations)
+        else:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager(pl, ent["ops"])
+            ent["graph"] = g
+            g.replay()
+        self.steps += 1
+        return self.loss
+
+
+class ModelManager:
+    """Name -> (init_model, prepare_data), as reference train.py:39-60.  Only the SlowFast path is accelerated;
+    'res2d' / 'res3d' are outside this engine's scope and raise like the reference does for
+    unknown names."""
+
+    def __init__(self, cfg, device="cuda", backend=None):
+        self.cfg, self.device, self.backend = cfg, device, backend
+        name = cfg.MODEL.NAME
+        if "slowfast" in name:
+            self.init_model = self._init_slowfast_model
+            self.prepare_data = self._prepare_slowfast_data
+        else:
+            raise NotImplementedError(f"MODEL.NAME={name!r}: only the SlowFast path runs on this engine")
+
+    @staticmethod
+    def delete_mismatch(state_dict):
+        """The 12 Kinetics-checkpoint tensors whose shapes differ from the ChaLearn model (train.py:93-111)."""
+        keys = ['blocks.0.multipathway_blocks.0.conv.weight', 'blocks.0.multipathway_blocks.1.conv.weight',
+                'blocks.6.proj.weight', 'blocks.6.proj.bias']
+        for b in (1, 2, 3, 4):
+            keys += [f'blocks.{b}.multipathway_blocks.0.res_blocks.0.branch1_conv.weight',
+                     f'blocks.{b}.multipathway_blocks.0.res_blocks.0.branch2.conv_a.weight']
+        for k in keys:
+            del state_dict[k]
+        return state_dict
+
+    def _init_slowfast_model(self):
+        model = init_my_slowfast(self.cfg, (5, 15), (64, 8), device=self.device, backend=self.backend)
+        ckpt = Path('pretrained', 'SLOWFAST_8x8_R50.pyth')          # train.py:116 (absent offline: random init)
+        if ckpt.is_file():
+            state = torch.load(ckpt, map_location="cpu", weights_only=True)["model_state"]
+            model.load_state_dict(self.delete_mismatch(state), strict=False)
+        else:
+            print(f'warning: {ckpt} not found, training from the reference init scheme')
+        return model
+
+    def _prepare_slowfast_data(self, batch):
+        """(N,T,21,S,S) -> [BGR+UV (N,5,T,S,S), flow (N,15,T,S,S)] strided views of the SAME memory; the depth channel
+        (20) is dropped (train.py:125-145).  The stem kernels read these views in place."""
+        x = batch[self.cfg.MODEL.R3D_INPUT].to(self.device, non_blocking=True)
+        x = torch.permute(x, [0, 2, 1, 3, 4])
+        y_true = batch['label'].to(self.device, non_blocking=True)
+        return [x[:, 0:5], x[:, 5:20]], y_true
+
+
+class SyntheticChalearn(torch.utils.data.Dataset):
+    """Stand-in with the item contract of the reference's ChalearnVideoDataset (dataset/chalearn_dataset.py:162-185):
+    train -> dict, test -> list of dicts (uniform windows), values normalised like ToTensor+Normalize(0.45, 0.225)."""
+
+    def __init__(self, cfg, name_of_set: str, num_videos: int = 8, clips_per_video=(1, 3), seed: int = 0):
+        self.cfg, self.name = cfg, name_of_set
+        self.key = cfg.MODEL.R3D_INPUT
+        self.size = crop_resize_dict[self.key]
+        self.t = cfg.CHALEARN.CLIP_LEN
+        g = torch.Generator().manual_seed(seed)
+        self.labels = torch.randint(0, cfg.CHALEARN.NUM_CLASS, (num_videos,), generator=g).tolist()
+        self.nclips = torch.randint(clips_per_video[0], clips_per_video[1] + 1, (num_videos,), generator=g).tolist()
+        self.seed = seed
+
+    def __len__(self):
+        return len(self.labels)
+
+    def _clip(self, i, j):
+        g = torch.Generator().manual_seed(self.seed * 7919 + i * 31 + j)
+        u8 = torch.randint(0, 256, (self.t, 21, self.size, self.size), generator=g, dtype=torch.uint8)
+        return {self.key: (u8.float() / 255.0 - 0.45) / 0.225, 'label': self.labels[i]}
+
+    def __getitem__(self, i):
+        if self.name == 'train':
+            return self._clip(i, 0)
+        return [self._clip(i, j) for j in range(self.nclips[i])]
+
+
+class Trainer:
+    def __init__(self, cfg, train_loader=None, test_loader=None, device="cuda", backend=None, use_graph: bool = True):
+        self.debug = cfg.DEBUG
+        self.num_workers = 0 if self.debug else min(cfg.NUM_CPU, 10)
+        self.cfg = cfg
+        self.batch_size = cfg.CHALEARN.BATCH_SIZE
+        self.rank, self.world, _ = sdist.init_process_group_from_env() if device != "cpu" else (0, 1, 0)
+        if train_loader is None or test_loader is None:
+            train_loader, test_loader = self._reference_loaders()
+        self.train_loader, self.test_loader = train_loader, test_loader
+        self.mm = ModelManager(cfg, device=device, backend=backend)
+        self.model = self.mm.init_model()
+        self.num_step = 0
+        self.ckpt_dir = Path(cfg.CHALEARN.ROOT, cfg.MODEL.LOGS, cfg.MODEL.CKPT_DIR, cfg.MODEL.NAME)
+        self.max_historical_acc = 0.
+        self.load_ckpt()
+        eng = self.model.engine
+        reducer = sdist.GradReducer(eng.G, bucket_mb=cfg.DIST.BUCKET_MB) if self.world > 1 else None
+        # Adam is created AFTER the checkpoint load, its state is never saved (train.py:180-182)
+        self.step = TrainStep(eng, lr=cfg.MODEL.LR, use_graph=use_graph, reducer=reducer)
+
+    def _reference_loaders(self):
+        try:
+            from dataset.chalearn_dataset import ChalearnVideoDataset   # the reference's module, unchanged
+        except Exception as e:  # cv2 / torchvision / label files missing
+            raise RuntimeError("no loaders were given and the reference's dataset.chalearn_dataset is not importable "
+                               f"here ({e}); pass train_loader/test_loader (e.g. SyntheticChalearn)") from e
+        tr = ChalearnVideoDataset(self.cfg, 'train')
+        te = ChalearnVideoDataset(self.cfg, 'test')
+        return (torch.utils.data.DataLoader(tr, batch_size=self.batch_size, shuffle=True, drop_last=True,
+                                            num_workers=self.num_workers),
+                torch.utils.data.DataLoader(te, batch_size=self.batch_size, shuffle=False, drop_last=False,
+                                            num_workers=self.num_workers, collate_fn=lambda x: x))
+
+    # ---- checkpoints: model weights only, 'acc%.3f_e%d.ckpt', newest by lexicographic sort, HTAH fallback
+    def save_ckpt(self, epoch=0, acc=0.0):
+        if self.rank != 0:
+            return
+        self.ckpt_dir.mkdir(parents=True, exist_ok=True)
+        ckpt_path = Path(self.ckpt_dir, 'acc%.3f_e%d.ckpt' % (acc, epoch))
+        if not self.debug:
+            torch.save({k: v.cpu() for k, v in self.model.state_dict().items()}, ckpt_path)
+            print(f"Checkpoint saved in {str(ckpt_path)}")
+        else:
+            print(f'Ignore checkpoint saving under debug mode. {str(ckpt_path)}')
+
+    def load_ckpt(self):
+        ckpt_list = sorted(glob.glob(str(self.ckpt_dir / '*.ckpt')))
+        if len(ckpt_list) == 0:
+            print('warning: no checkpoint found, try using HTAH ckeckpoint')
+            ckpt_list = sorted(glob.glob(str(Path(self.ckpt_dir.parent, 'slowfast-HTAH', '*.ckpt'))))
+            if len(ckpt_list) == 0:
+                print('warning: no HTAH checkpoint found')
+                return
+        ckpt = ckpt_list[-1]
+        print(f'loading checkpoint from {str(ckpt)}')
+        self.model.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=True), strict=True)
+
+    def train_epoch(self):
+        self.step.reset_meters()
+        seen = 0
+        self.model.train()
+        for batch in self.train_loader:
+            x, y_true = self.mm.prepare_data(batch)
+            self.step(x[0], x[1], y_true)
+            self.num_step += 1
+            seen += int(y_true.shape[0])
+            if self.debug:
+                break
+        # one device->host read per epoch instead of one per step
+        loss_avg = float(self.step.loss_sum[0]) / max(self.step.steps, 1)
+        correct = int(self.step.correct[0])
+        print(f'loss_avg: {round(loss_avg, 3)}')
+        print(f'Train Accuracy: {round(correct / max(seen, 1), 3)}. ({correct} / {seen})')
+        return loss_avg, correct / max(seen, 1)
+
+    def train(self):
+        max_epoch = self.cfg.MODEL.MAX_EPOCH if not self.debug else 3
+        acc, epoch = 0.0, 0
+        for epoch in range(max_epoch):
+            print(f'========== Training epoch {epoch}')
+            self.num_step = 0
+            self.train_epoch()
+            acc = self.run_eval()['acc']
+            if acc > self.max_historical_acc:
+                self.max_historical_acc = acc
+                self.save_ckpt(epoch, acc)
+            else:
+                print("Not saved. Current best acc: %.3f" % (self.max_historical_acc))
+        self.save_ckpt(epoch, acc)
+
+    def run_eval(self, dataset_loader=None):
+        """Batched no-grad forward over uniform windows; softmax; per-video mean over its clips; argmax
+        (train.py:287-370).  Returns {'ps','t','acc','sv'} as train_sparse.py:76-84 consumes it."""
+        loader = self.test_loader if dataset_loader is None else dataset_loader
+        pred_score_list, true_list, batch_collect, samples_per_video = [], [], [], []
+        self.model.eval()
+
+        def test_batch(collect):
+            x, y_true = self.mm.prepare_data(collect)
+            with torch.no_grad():
+                y_pred = self.model(x)
+            pred_score_list.append(y_pred.float().cpu().numpy())
+            true_list.append(y_true.cpu().numpy())
+
+        for step, batch in enumerate(loader):
+            for b in batch:
+                samples_per_video.append(len(b))
+                batch_collect.extend(b)
+            if len(batch_collect) < self.batch_size:
+                continue
+            while len(batch_collect) > self.batch_size:          # strict '>' as the reference (train.py:322)
+                test_batch(default_collate(batch_collect[:self.batch_size]))
+                batch_collect = batch_collect[self.batch_size:]
+            if self.debug and step > 5:
+                break
+        if len(batch_collect) > 0:
+            test_batch(default_collate(batch_collect))
+        ps = np.concatenate(pred_score_list, axis=0)
+        ps = np.exp(ps) / np.sum(np.exp(ps), axis=1, keepdims=True)
+        true_arr = np.concatenate(true_list, axis=0)
+        correct_list, read_index = [], 0
+        for num_samples in samples_per_video:
+            preds = ps[read_index: read_index + num_samples]
+            trues = true_arr[read_index: read_index + num_samples]
+            read_index += num_samples
+            if len(preds) == 0:
+                continue
+            assert np.all(trues == trues[0])
+            correct_list.append(np.argmax(np.mean(preds, axis=0), axis=0) == trues[0])
+        c = np.array(correct_list)
+        accuracy = c.sum() / max(len(c), 1)
+        print(f'Test Accuracy: {round(float(accuracy), 3)}. ({c.sum()} / {len(c)})')
+        return {'ps': ps, 't': true_arr, 'acc': accuracy, 'sv': samples_per_video}
