@@ -57,6 +57,11 @@ def instrumented_step(step, pl, frames, labels, idx):
     ops["adam"](st)
     torch.cuda.synchronize()
     out = {}
+    if os.environ.get("SFK_PER_LAYER"):
+        rows = [dict(meta, ms=a.elapsed_time(b)) for meta, a, b in ev]
+        os.makedirs(os.path.dirname(os.environ["SFK_PER_LAYER"]) or ".", exist_ok=True)
+        with open(os.environ["SFK_PER_LAYER"], "w") as f:
+            json.dump(rows, f)
     for meta, a, b in ev:
         kind = meta["kind"]
         if kind in ("conv_fwd", "conv_dgrad"):
