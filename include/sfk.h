@@ -137,6 +137,34 @@ typedef struct {
 int sfk_stem_im2col(const sfk_im2col_desc* d, sfk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * sfk_stem_conv_fwd / sfk_stem_conv_wgrad -- the stem Conv3d (kt,7,7) stride (1,2,2) padding (kt/2,3,3), bias=False
+ * (my_slowfast.py:63-65 via create_res_basic_stem; canonical fast stem (5,7,7)), computed directly from the clip:
+ * the input patch of a 16x16 output tile is staged once in LDS and every MFMA operand is built from it (an implicit
+ * GEMM would re-read K*2 B = 1.5 KB per output pixel).  Also replaces the views of _prepare_slowfast_data
+ * (train.py:136-140) and PackPathway's frame gather ((deprecated)/(torchvideo)train.py:60-71): the clip is read in
+ * place through element strides, frame(t) = t_index ? t_index[t] : t (t_len logical frames).
+ * Filter layout ("stem layout", compute dtype for fwd, fp32 for the gradient):
+ *     w[co][ ((f*cin + ci)*7 + kh)*8 + kw ],  kw = 7 and rows beyond kt*cin*7 are ZERO padding;
+ *     row length kp = sfk_stem_kp(cin, kt).  The gradient kernel never writes the padding.
+ * y / dy: channels-last (n, t_len, ho, wo, cout), cout % 4 == 0, cout <= 64.
+ * stats: optional [sfk_stem_conv_tiles(...)][cout][2] BatchNorm partial sums, as sfk_conv_igemm.
+ */
+typedef struct {
+  const void* src;
+  int32_t src_dtype; /* SFK_F32 or SFK_BF16 */
+  int64_t sn, sc, st, sh, sw; /* element strides of (n, ci, t, h, w) */
+  int32_t cin, t_in, h_in, w_in;
+  const int32_t* t_index; /* device, t_len entries, or NULL (then t_len is ignored and t_in frames are used) */
+  int32_t t_len;
+  int32_t kt;
+} sfk_stem_src;
+
+int sfk_stem_kp(int32_t cin, int32_t kt);
+int sfk_stem_conv_tiles(const sfk_stem_src* s, const sfk_fmap* y);
+int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk_fmap* y, float* stats, sfk_stream_t stream);
+int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, float* dw, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * BatchNorm3d (eps, momentum; affine; running stats) -- nn.BatchNorm3d after every conv
  * (my_slowfast.py:143-146,215-222; pytorchvideo stems / bottlenecks), ReLU (nn.ReLU), the residual
  * add of pytorchvideo ResBlock and their autograd.  All per-channel vectors are fp32.

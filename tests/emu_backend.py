@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from video_classification_amd._lib import ConvPass, FMap, Im2col, WgradPass
+from video_classification_amd._lib import ConvPass, FMap, Im2col, StemSrc, WgradPass, stem_kp
 
 
 def _tile_bm(cout: int) -> int:
@@ -118,6 +118,51 @@ class EmuBackend:
                     base = (kh * p.kw + kw) * c
                     cols[..., base:base + c] = patch.permute(0, 2, 3, 4, 1)
             o.view5().copy_(cols.to(o.dtype))
+        return run
+
+    # ------------------------------------------------------------------ stem convolution (direct)
+    @staticmethod
+    def _stem_x(p: StemSrc, dtype):
+        x = p.src.to(dtype).float()          # the clip is rounded to the compute precision when the patch is staged
+        if p.t_index is not None:
+            x = x.index_select(2, p.t_index.long())
+        return x
+
+    @staticmethod
+    def stem_weight_from_layout(w, cout, cin, kt):
+        """[co][((f*cin+ci)*7+kh)*8+kw] -> (co, ci, kt, 7, 7)"""
+        kp = stem_kp(cin, kt)
+        w = w[: cout * kp].view(cout, kp)[:, : kt * cin * 7 * 8].view(cout, kt, cin, 7, 8)[..., :7]
+        return w.permute(0, 2, 1, 3, 4).float()
+
+    def stem_conv_tiles(self, p: StemSrc, y: FMap) -> int:
+        return y.n * y.t * ((y.h + 15) // 16) * ((y.w + 15) // 16)
+
+    def stem_conv_fwd(self, p: StemSrc, w, y: FMap, stats):
+        def run(stream):
+            x = self._stem_x(p, y.dtype)
+            wt = self.stem_weight_from_layout(w, y.c, x.shape[1], p.kt)
+            out = torch.nn.functional.conv3d(x, wt, None, (1, 2, 2), (p.kt // 2, 3, 3))   # n co t ho wo
+            y.view5().copy_(out.permute(0, 2, 3, 4, 1).to(y.dtype))
+            if stats is not None:
+                mt = self.stem_conv_tiles(p, y)
+                st = stats[: mt * y.c * 2].view(mt, y.c, 2)
+                st.zero_()
+                st[0, :, 0] = out.sum((0, 2, 3, 4))
+                st[0, :, 1] = (out * out).sum((0, 2, 3, 4))
+        return run
+
+    def stem_conv_wgrad(self, p: StemSrc, dy: FMap, dw):
+        def run(stream):
+            x = self._stem_x(p, dy.dtype)
+            cin, cout, kt = x.shape[1], dy.c, p.kt
+            with torch.enable_grad():        # the engine's backward runs inside autograd's no_grad region
+                wt = torch.zeros(cout, cin, kt, 7, 7, requires_grad=True)
+                out = torch.nn.functional.conv3d(x.detach(), wt, None, (1, 2, 2), (kt // 2, 3, 3))
+                out.backward(dy.view5().float().permute(0, 4, 1, 2, 3))
+            kp = stem_kp(cin, kt)
+            g = torch.nn.functional.pad(wt.grad.permute(0, 2, 1, 3, 4), (0, 1)).reshape(cout, kt * cin * 7 * 8)
+            dw[: cout * kp].view(cout, kp)[:, : g.shape[1]] += g
         return run
 
     # ------------------------------------------------------------------ batch norm

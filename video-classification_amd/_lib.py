@@ -99,6 +99,22 @@ class WgradPass:
 
 
 @dataclass
+class StemSrc:
+    src: torch.Tensor        # any strided view indexed (n, c, t, h, w), f32 or bf16, read in place
+    t_index: Optional[torch.Tensor]   # int32 frame indices (PackPathway) or None
+    kt: int
+
+    @property
+    def t_len(self) -> int:
+        return int(self.t_index.numel()) if self.t_index is not None else int(self.src.shape[2])
+
+
+def stem_kp(cin: int, kt: int) -> int:
+    """row length of the stem filter layout [co][((f*cin+ci)*7+kh)*8+kw] (mirrors sfk_stem_kp)"""
+    return (kt * cin * 7 + 3) // 4 * 4 * 8
+
+
+@dataclass
 class Im2col:
     src: torch.Tensor        # any strided view indexed (n, c, t, h, w)
     t_index: Optional[torch.Tensor]
@@ -140,6 +156,13 @@ class _Im2colDesc(C.Structure):
                 ("pad_w", C.c_int32), ("out", _FMap)]
 
 
+class _StemSrc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_dtype", C.c_int32), ("sn", C.c_int64), ("sc", C.c_int64),
+                ("st", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("cin", C.c_int32), ("t_in", C.c_int32),
+                ("h_in", C.c_int32), ("w_in", C.c_int32), ("t_index", C.c_void_p), ("t_len", C.c_int32),
+                ("kt", C.c_int32)]
+
+
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)
 
@@ -149,6 +172,10 @@ SIGNATURES = {
     "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
+    "sfk_stem_kp": [_I32, _I32],
+    "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
+    "sfk_stem_conv_fwd": [C.POINTER(_StemSrc), _PV, _P_FMAP, _PF, _PV],
+    "sfk_stem_conv_wgrad": [C.POINTER(_StemSrc), _P_FMAP, _PF, _PV],
     "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
     "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
@@ -293,6 +320,34 @@ class HipBackend:
             if st:
                 _check(st, "sfk_stem_im2col")
         return run
+
+    @staticmethod
+    def _c_stem(p: StemSrc) -> _StemSrc:
+        s = p.src
+        assert s.dim() == 5
+        d = _StemSrc()
+        d.src, d.src_dtype = s.data_ptr(), _DT[s.dtype]
+        d.sn, d.sc, d.st, d.sh, d.sw = s.stride()
+        d.cin, d.t_in, d.h_in, d.w_in = s.shape[1], s.shape[2], s.shape[3], s.shape[4]
+        d.t_index = _ptr(p.t_index)
+        d.t_len = p.t_len
+        d.kt = p.kt
+        return d
+
+    def stem_conv_tiles(self, p: StemSrc, y: FMap) -> int:
+        d, fy = self._c_stem(p), _c_fmap(y)
+        r = self.lib.sfk_stem_conv_tiles(C.byref(d), C.byref(fy))
+        if r < 0:
+            _check(r, "sfk_stem_conv_tiles")
+        return r
+
+    def stem_conv_fwd(self, p: StemSrc, w: torch.Tensor, y: FMap, stats: Optional[torch.Tensor]):
+        d, fy = self._c_stem(p), _c_fmap(y)
+        return self._plain("sfk_stem_conv_fwd", C.byref(d), _ptr(w), C.byref(fy), _ptr(stats), keep=(d, fy, p, w, y, stats))
+
+    def stem_conv_wgrad(self, p: StemSrc, dy: FMap, dw: torch.Tensor):
+        d, fy = self._c_stem(p), _c_fmap(dy)
+        return self._plain("sfk_stem_conv_wgrad", C.byref(d), C.byref(fy), _ptr(dw), keep=(d, fy, p, dy, dw))
 
     # -- generic plain-argument entry points
     def _plain(self, name, *args, keep=()):

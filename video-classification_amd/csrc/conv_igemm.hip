@@ -26,6 +26,7 @@ struct ConvK {
   int gst, gsh, gsw, ost, osh, osw, oot, ooh, oow;
   int cin, cout, wtaps, ntaps, KC, accumulate;
   int mtiles, ntiles;
+  FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -97,6 +98,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   constexpr int BUF = (BM + BN) * ROWB;
   static_assert(WM * WN == 4 && BM % RPI == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ sfk_tap s_taps[SFK_MAX_TAPS + 1];   // + a sentinel that gathers nothing (K tail)
+  if (threadIdx.x <= SFK_MAX_TAPS) {
+    sfk_tap t = k.taps[threadIdx.x < SFK_MAX_TAPS ? threadIdx.x : 0];
+    if ((int)threadIdx.x >= k.ntaps) { t.dt = -128; t.dh = 0; t.dw = 0; t.widx = 0; }
+    s_taps[threadIdx.x] = t;
+  }
+  __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -130,11 +138,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   const T* __restrict__ xp = static_cast<const T*>(k.x);
   const T* __restrict__ wp = static_cast<const T*>(k.w);
 
+  // K is the flattened (tap, channel) axis cut into 16-byte segments; a K-step takes SEGS consecutive segments, so
+  // narrow layers (cin < 32) pack several taps into one MFMA step instead of padding each tap to 32 channels.
   uint4 xr[XL], wr[WL];
-  auto gload = [&](int tap, int kc) {
-    const sfk_tap tp = k.taps[tap];
-    const int c = kc * BK + seg * VEC;
-    const bool cok = c < k.cin;
+  const int spt = (int)k.dspt.d;
+  auto gload = [&](int step) {
+    const uint32_t q = (uint32_t)(step * SEGS + seg);
+    uint32_t tap, cseg;
+    k.dspt.divmod(q, tap, cseg);
+    const sfk_tap tp = s_taps[tap < (uint32_t)k.ntaps ? tap : SFK_MAX_TAPS];
+    const bool cok = tap < (uint32_t)k.ntaps;
+    const int c = (int)cseg * VEC;
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int ti = xtb[i] + tp.dt, hi = xhb[i] + tp.dh, wi = xwb[i] + tp.dw;
@@ -170,16 +184,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nit = k.ntaps * k.KC;
-  int tap = 0, kc = 0;
-  gload(0, 0);
+  const int nit = k.KC;
+  gload(0);
   lstore(0);
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
-    if (++kc == k.KC) { kc = 0; ++tap; }
     const bool more = it + 1 < nit;
-    if (more) gload(tap, kc);
+    if (more) gload(it + 1);
     const char* xs = smem + buf * BUF;
     const char* ws = xs + BM * ROWB;
     typename TL::frag a[FN], b[FM];
@@ -302,7 +314,9 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.ost = d->os[0]; k.osh = d->os[1]; k.osw = d->os[2];
   k.oot = d->oo[0]; k.ooh = d->oo[1]; k.oow = d->oo[2];
   k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
-  k.KC = (d->cin + BK - 1) / BK;
+  const int vec = sfk_vec_of(d->x.dtype), segs = BK / vec;
+  k.dspt.set(d->cin / vec);
+  k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
   const TileSel ts = pick_tile(d->cout);

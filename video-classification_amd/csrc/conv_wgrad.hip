@@ -6,7 +6,9 @@
 // staged as they lie in HBM ([pixel][channel] rows, 16 B per lane) and the MFMA fragments (8 consecutive pixels
 // of one channel per lane) come out of LDS already transposed:
 //   bf16: ds_read_b64_tr_b16 (two per fragment)          f32: one ds_read_b32 per MFMA (one k per lane)
-// Grid = (co-tile x ci-tile, tap, pixel-split); partial tiles are combined with fp32 atomics into dW.
+// The (tap, cin) axis is flattened into the GEMM's column space and gathered per 16-byte segment (as the forward
+// kernel packs its K axis), so the taps of narrow layers share one tile and dY is read once per column tile.
+// Grid = (co-tile x column-tile, 1, pixel-split); partial tiles are combined with fp32 atomics into dW.
 #include "sfk_common.h"
 
 namespace {
@@ -20,9 +22,10 @@ struct WgradK {
   int M;
   FastDiv drw, drh, drt;
   int gst, gsh, gsw;
-  int cin, cout, wtaps;
-  int citiles;
-  int chunks_per_split, nchunks;
+  int cin, cout, wtaps, ntaps;
+  int citiles;                    // column tiles over the flattened (tap, cin) axis
+  int chunks_per_split, nchunks;  // in stages of KS*32 pixels
+  FastDiv dspt, dcin;             // 16-byte segments per tap; channels per tap
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -50,9 +53,10 @@ template <int TC> struct WT<bf16_t, TC> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
   }
 };
+struct F32Frag { float v[8]; };
 template <int TC> struct WT<float, TC> {
   static constexpr int VEC = 4, SEGS = TC / 4, ROWB = TC * 4 + 16;
-  struct frag { float v[8]; };
+  typedef F32Frag frag;
   // MFMA step s takes pixel 4s+g of channel c0 + (lane&15)
   static __device__ __forceinline__ frag load(const char* tile, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
@@ -67,106 +71,140 @@ template <int TC> struct WT<float, TC> {
   }
 };
 
-// TC = tile edge in channels (both co and ci); 4 waves as 2 x 2, each (TC/2) x (TC/2)
-template <typename T, int TC>
+// Block tile: TCO output channels x TCI columns of the flattened (tap, cin) axis; 4 waves as 2 x 2.  A stage is
+// KS K-steps (KS*32 pixels) between two barriers.  Column segments (16 B) are gathered independently, so a tile may
+// straddle taps and narrow layers put ALL their taps into one tile (9 x 8 channels = 72 columns).
+template <typename T, int TCO, int TCI, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
-  using W = WT<T, TC>;
-  constexpr int VEC = W::VEC, SEGS = W::SEGS, ROWB = W::ROWB;
-  constexpr int F = TC / 2 / 16;                 // fragments per wave per side
-  constexpr int NL = (MK * SEGS + 255) / 256;    // 16-byte loads per thread per operand per K-step
-  constexpr int BUF = 2 * MK * ROWB;             // dY tile + X tile
+  using WO = WT<T, TCO>;
+  using WI = WT<T, TCI>;
+  constexpr int VEC = WO::VEC;
+  constexpr int SEGO = WO::SEGS, SEGI = WI::SEGS, ROWO = WO::ROWB, ROWI = WI::ROWB;
+  constexpr int R = MK * KS;                       // pixels per stage
+  constexpr int FO = TCO / 32, FI = TCI / 32;      // 16-wide fragments per wave (co side, column side)
+  constexpr int NLO = (R * SEGO + 255) / 256, NLI = (R * SEGI + 255) / 256;
+  constexpr int TILEO = R * ROWO, TILEI = R * ROWI, BUF = TILEO + TILEI;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ sfk_tap s_taps[SFK_MAX_TAPS + 1];
+  if (threadIdx.x <= SFK_MAX_TAPS) {
+    sfk_tap t = k.taps[threadIdx.x < SFK_MAX_TAPS ? threadIdx.x : 0];
+    if ((int)threadIdx.x >= k.ntaps) { t.dt = -128; t.dh = 0; t.dw = 0; t.widx = 0; }
+    s_taps[threadIdx.x] = t;
+  }
+  __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave & 1, wci = wave >> 1;
   const int cot = blockIdx.x / k.citiles, cit = blockIdx.x % k.citiles;
-  const sfk_tap tp = k.taps[blockIdx.y];
-  const int chunk0 = blockIdx.z * k.chunks_per_split;
-  const int chunk1 = min(chunk0 + k.chunks_per_split, k.nchunks);
+  const int stage0 = blockIdx.z * k.chunks_per_split;
+  const int stage1 = min(stage0 + k.chunks_per_split, k.nchunks);
+  if (stage0 >= stage1) return;
 
   const T* __restrict__ xp = static_cast<const T*>(k.x);
   const T* __restrict__ dp = static_cast<const T*>(k.dy);
 
-  uint4 dr[NL], xr[NL];
-  auto gload = [&](int chunk) {
+  // column segment -> (tap, channel) of this thread's X slots (fixed for the whole kernel)
+  int xi_row[NLI], xi_soff[NLI], xi_c[NLI];
+  sfk_tap xi_tap[NLI];
+  bool xi_ok[NLI];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+  for (int i = 0; i < NLI; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / SEGI, seg = idx % SEGI;
+    uint32_t tap, cseg;
+    k.dspt.divmod((uint32_t)(cit * SEGI + seg), tap, cseg);
+    xi_ok[i] = idx < R * SEGI && tap < (uint32_t)k.ntaps;
+    xi_tap[i] = s_taps[tap < (uint32_t)k.ntaps ? tap : SFK_MAX_TAPS];
+    xi_row[i] = row;
+    xi_soff[i] = row * ROWI + seg * 16;
+    xi_c[i] = (int)cseg * VEC;
+  }
+  uint4 dr[NLO], xr[NLI];
+  auto gload = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NLO; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx / SEGS, seg = idx % SEGS;
-      const int m = chunk * MK + row;
-      const bool rok = (MK * SEGS >= 256 || idx < MK * SEGS) && m < k.M;
+      const int row = idx / SEGO, seg = idx % SEGO;
+      const int m = stage * R + row;
+      const int co = cot * TCO + seg * VEC;
+      const bool ok = idx < R * SEGO && m < k.M && co < k.cout;
+      dr[i] = ok ? *reinterpret_cast<const uint4*>(dp + (int64_t)m * k.dld + k.doff + co) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLI; ++i) {
+      const int m = stage * R + xi_row[i];
       uint32_t q1, rw_, q2, rh_, n_, rt_;
       k.drw.divmod((uint32_t)m, q1, rw_);
       k.drh.divmod(q1, q2, rh_);
       k.drt.divmod(q2, n_, rt_);
-      const int co = cot * TC + seg * VEC;
-      dr[i] = (rok && co < k.cout) ? *reinterpret_cast<const uint4*>(dp + (int64_t)m * k.dld + k.doff + co)
-                                   : make_uint4(0, 0, 0, 0);
-      const int ci = cit * TC + seg * VEC;
-      const int ti = (int)rt_ * k.gst + tp.dt, hi = (int)rh_ * k.gsh + tp.dh, wi = (int)rw_ * k.gsw + tp.dw;
-      const bool xok = rok && ci < k.cin && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
-                       (unsigned)wi < (unsigned)k.xw;
-      const int64_t off = ((((int64_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi) * k.xld + k.xoff + ci;
-      xr[i] = xok ? *reinterpret_cast<const uint4*>(xp + off) : make_uint4(0, 0, 0, 0);
+      const int ti = (int)rt_ * k.gst + xi_tap[i].dt, hi = (int)rh_ * k.gsh + xi_tap[i].dh,
+                wi = (int)rw_ * k.gsw + xi_tap[i].dw;
+      const bool ok = xi_ok[i] && m < k.M && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
+                      (unsigned)wi < (unsigned)k.xw;
+      const int64_t off = ((((int64_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi) * k.xld + k.xoff + xi_c[i];
+      xr[i] = ok ? *reinterpret_cast<const uint4*>(xp + off) : make_uint4(0, 0, 0, 0);
     }
   };
   auto lstore = [&](int buf) {
     char* ds = smem + buf * BUF;
-    char* xs = ds + MK * ROWB;
+    char* xs = ds + TILEO;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < NLO; ++i) {
       const int idx = tid + i * 256;
-      if (MK * SEGS >= 256 || idx < MK * SEGS) {
-        const int row = idx / SEGS, seg = idx % SEGS;
-        *reinterpret_cast<uint4*>(ds + row * ROWB + seg * 16) = dr[i];
-        *reinterpret_cast<uint4*>(xs + row * ROWB + seg * 16) = xr[i];
-      }
+      if (idx < R * SEGO) *reinterpret_cast<uint4*>(ds + (idx / SEGO) * ROWO + (idx % SEGO) * 16) = dr[i];
     }
+#pragma unroll
+    for (int i = 0; i < NLI; ++i)
+      if (tid + i * 256 < R * SEGI) *reinterpret_cast<uint4*>(xs + xi_soff[i]) = xr[i];
   };
 
-  f32x4 acc[F][F];
+  f32x4 acc[FO][FI];
 #pragma unroll
-  for (int i = 0; i < F; ++i)
+  for (int i = 0; i < FO; ++i)
 #pragma unroll
-    for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (chunk0 < chunk1) {
-    gload(chunk0);
-    lstore(0);
-    __syncthreads();
-    for (int ch = chunk0; ch < chunk1; ++ch) {
-      const int buf = (ch - chunk0) & 1;
-      const bool more = ch + 1 < chunk1;
-      if (more) gload(ch + 1);
-      const char* ds = smem + buf * BUF;
-      const char* xs = ds + MK * ROWB;
-      typename W::frag a[F], b[F];
+  gload(stage0);
+  lstore(0);
+  __syncthreads();
+  for (int st = stage0; st < stage1; ++st) {
+    const int buf = (st - stage0) & 1;
+    const bool more = st + 1 < stage1;
+    if (more) gload(st + 1);
+    const char* ds = smem + buf * BUF;
+    const char* xs = ds + TILEO;
 #pragma unroll
-      for (int i = 0; i < F; ++i) a[i] = W::load(ds, wco * (TC / 2) + 16 * i, lane);
+    for (int ks = 0; ks < KS; ++ks) {
+      typename WO::frag a[FO];
+      typename WI::frag b[FI];
 #pragma unroll
-      for (int j = 0; j < F; ++j) b[j] = W::load(xs, wci * (TC / 2) + 16 * j, lane);
+      for (int i = 0; i < FO; ++i) a[i] = WO::load(ds + ks * MK * ROWO, wco * (TCO / 2) + 16 * i, lane);
 #pragma unroll
-      for (int i = 0; i < F; ++i)
+      for (int j = 0; j < FI; ++j) b[j] = WI::load(xs + ks * MK * ROWI, wci * (TCI / 2) + 16 * j, lane);
 #pragma unroll
-        for (int j = 0; j < F; ++j) W::mma(acc[i][j], a[i], b[j]);
-      if (more) lstore(buf ^ 1);
-      __syncthreads();
+      for (int i = 0; i < FO; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) WO::mma(acc[i][j], a[i], b[j]);
     }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
   }
 
-  // D[row = co][col = ci]: lane holds co = 4*(lane>>4) + r, ci = lane & 15 -> 16 lanes add 16 consecutive floats
+  // D[row = co][col]: lane holds co = 4*(lane>>4) + r and column lane & 15 -> 16 lanes add 16 consecutive floats
   const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < F; ++i) {
+  for (int j = 0; j < FI; ++j) {
+    const int col = cit * TCI + wci * (TCI / 2) + 16 * j + l15;
+    uint32_t tap, ci;
+    k.dcin.divmod((uint32_t)col, tap, ci);
+    if (tap >= (uint32_t)k.ntaps) continue;
+    const int widx = s_taps[tap].widx;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cot * TC + wco * (TC / 2) + 16 * i + 4 * g + r;
-      if (co >= k.cout) continue;
-      float* rowp = k.dw + ((int64_t)co * k.wtaps + tp.widx) * k.cin;
+    for (int i = 0; i < FO; ++i) {
 #pragma unroll
-      for (int j = 0; j < F; ++j) {
-        const int ci = cit * TC + wci * (TC / 2) + 16 * j + l15;
-        if (ci < k.cin) atomicAdd(rowp + ci, acc[i][j][r]);
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * TCO + wco * (TCO / 2) + 16 * i + 4 * g + r;
+        if (co < k.cout) atomicAdd(k.dw + ((int64_t)co * k.wtaps + widx) * k.cin + ci, acc[i][j][r]);
       }
     }
   }
@@ -187,6 +225,27 @@ int validate(const sfk_wgrad_desc* d) {
   return SFK_OK;
 }
 
+template <typename T, int TCO, int TCI, int KS>
+int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
+  const int cols = d->ntaps * d->cin;
+  const int cotiles = (d->cout + TCO - 1) / TCO;
+  k.citiles = (cols + TCI - 1) / TCI;
+  constexpr int R = MK * KS;
+  k.nchunks = (k.M + R - 1) / R;
+  // pixel splits: enough workgroups to cover the 256 CUs several times, at least 4 stages each
+  const int base = cotiles * k.citiles;
+  int splits = (2048 + base - 1) / base;
+  const int max_splits = (k.nchunks + 3) / 4;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  k.chunks_per_split = (k.nchunks + splits - 1) / splits;
+  splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)base, 1, (unsigned)splits), dim3(256), 0, s, k);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
 template <typename T>
 int launch(const sfk_wgrad_desc* d, hipStream_t s) {
   WgradK k;
@@ -196,26 +255,19 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s) {
   k.M = (int)sfk_fmap_pixels(&d->dy);
   k.drw.set(d->dy.w); k.drh.set(d->dy.h); k.drt.set(d->dy.t);
   k.gst = d->gs[0]; k.gsh = d->gs[1]; k.gsw = d->gs[2];
-  k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps;
+  k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
+  k.dspt.set(d->cin / sfk_vec_of(d->x.dtype));
+  k.dcin.set(d->cin);
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  const int tc = (d->cin >= 128 && d->cout >= 128) ? 128 : 64;
-  const int cotiles = (d->cout + tc - 1) / tc;
-  k.citiles = (d->cin + tc - 1) / tc;
-  k.nchunks = (k.M + MK - 1) / MK;
-  // pixel splits: enough workgroups to cover the 256 CUs a few times, at least 8 K-steps each
-  const int base = cotiles * k.citiles * d->ntaps;
-  int splits = (1024 + base - 1) / base;
-  const int max_splits = (k.nchunks + 7) / 8;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
-  k.chunks_per_split = (k.nchunks + splits - 1) / splits;
-  splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
-  const dim3 grid((unsigned)(cotiles * k.citiles), (unsigned)d->ntaps, (unsigned)splits), block(256);
-  if (tc == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, block, 0, s, k);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, block, 0, s, k);
-  SFK_CHECK_LAUNCH();
-  return SFK_OK;
+  const int cols = d->ntaps * d->cin;
+  if (cols <= 32) {
+    if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s);
+    if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s);
+    return launch_cfg<T, 128, 32, 2>(k, d, s);
+  }
+  if (d->cout <= 32) return launch_cfg<T, 32, 128, 2>(k, d, s);
+  if (d->cout <= 64) return launch_cfg<T, 64, 128, 2>(k, d, s);
+  return launch_cfg<T, 128, 128, 1>(k, d, s);
 }
 
 }  // namespace

@@ -20,7 +20,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import arch
-from ._lib import ConvPass, FMap, Im2col, WgradPass
+from ._lib import ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
@@ -79,7 +79,7 @@ class Plan:
         self.key = None
         # (index one past the backward op that finishes it, (arena offset, numel)): every gradient range has ONE writer
         self.grad_marks: List[Tuple[int, Tuple[int, int]]] = []
-        self.im2col_slots: List[Tuple[int, int]] = []     # (index in fwd, pathway) of the ops bound to the input tensors
+        self.stem_state: Dict[int, dict] = {}             # per pathway: buffers + slots of the ops bound to the clip tensors
 
     def grad_segments(self, nseg: int) -> List[Tuple[int, int, List[Tuple[int, int]]]]:
         """Cut the backward schedule into nseg pieces [(op_begin, op_end, finished gradient ranges)], balanced by
@@ -125,10 +125,11 @@ class Engine:
         for cb in W.all_convbn():
             g = cb.geom
             if cb.is_stem:
-                kreal = g.k[1] * g.k[2] * g.cin
-                kpad = round_up(kreal, self.vec)
-                eg = ConvGeom(kpad, g.cout, (g.k[0], 1, 1), (1, 1, 1), (g.k[0] // 2, 0, 0))
-                L = _Layer(cb, eg, kreal, needs_dgrad=False)
+                # stem filters live in the stem layout [co][((f*cin+ci)*7+kh)*8+kw] (sfk_stem_conv_fwd)
+                assert g.k[1:] == (7, 7) and g.s == (1, 2, 2) and g.p == (g.k[0] // 2, 3, 3), g
+                kp = stem_kp(g.cin, g.k[0])
+                eg = ConvGeom(kp, g.cout, (1, 1, 1))          # one row of kp "channels" per output channel
+                L = _Layer(cb, eg, g.k[0] * g.cin * 7 * 8, needs_dgrad=False)
             else:
                 assert g.cin % self.vec == 0 and g.cout % 4 == 0, (cb.conv_key, g)
                 L = _Layer(cb, g, 0)
@@ -197,18 +198,19 @@ class Engine:
     def _to_engine_layout(self, L: _Layer, w: torch.Tensor) -> torch.Tensor:
         """(cout, cin, kt, kh, kw) -> flat [cout][tap][cin]  (stems: [cout][kt][(kh,kw,cin) zero-padded])."""
         g = L.cb.geom
-        w = w.reshape(g.cout, g.cin, *g.k).permute(0, 2, 3, 4, 1)  # co, kt, kh, kw, ci
+        w = w.reshape(g.cout, g.cin, *g.k)
         if L.cb.is_stem:
-            w = w.reshape(g.cout, g.k[0], L.kreal)
-            w = torch.nn.functional.pad(w, (0, L.eg.cin - L.kreal))
-        return w.reshape(-1).float()
+            w = torch.nn.functional.pad(w.permute(0, 2, 1, 3, 4), (0, 1))           # co, kt, ci, kh, kw(7 -> 8)
+            w = torch.nn.functional.pad(w.reshape(g.cout, L.kreal), (0, L.eg.cin - L.kreal))
+            return w.reshape(-1).float()
+        return w.permute(0, 2, 3, 4, 1).reshape(-1).float()              # co, kt, kh, kw, ci
 
     def _from_engine_layout(self, L: _Layer, flat: torch.Tensor) -> torch.Tensor:
         g = L.cb.geom
         if L.cb.is_stem:
-            w = flat.reshape(g.cout, g.k[0], L.eg.cin)[..., :L.kreal].reshape(g.cout, g.k[0], g.k[1], g.k[2], g.cin)
-        else:
-            w = flat.reshape(g.cout, g.k[0], g.k[1], g.k[2], g.cin)
+            w = flat.reshape(g.cout, L.eg.cin)[:, :L.kreal].reshape(g.cout, g.k[0], g.cin, 7, 8)[..., :7]
+            return w.permute(0, 2, 1, 3, 4).contiguous()
+        w = flat.reshape(g.cout, g.k[0], g.k[1], g.k[2], g.cin)
         return w.permute(0, 4, 1, 2, 3).contiguous()
 
     # checkpoint surface: flat dict with pytorchvideo key names, fp32, reference tensor shapes
@@ -397,7 +399,31 @@ class Engine:
                           bytes=float(esz * (dy.pixels * L.eg.cout / len(passes) + rows * L.eg.cin * (2 if accumulate else 1)
                                              + L.w_numel)))
 
-    # ---- stem: im2col -> temporal conv -> BN -> ReLU -> MaxPool
+    # ---- stem: direct (kt,7,7)/(1,2,2) conv from the clip -> BN -> ReLU -> MaxPool
+    def _stem_ops(self, pl: Plan, p: int, x5: torch.Tensor, t_index, rec=None):
+        """(re)create the two ops that hold the clip's address: forward conv and filter gradient"""
+        L = self._layers[self.wiring.stems[p].conv_key]
+        src = StemSrc(x5, t_index, L.cb.geom.k[0])
+        st = pl.stem_state[p]
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        flops = 2.0 * st["y"].pixels * L.c * L.cb.geom.cin * L.cb.geom.wtaps
+        fwd = self.be.stem_conv_fwd(src, self.S[L.w_off:L.w_off + L.w_numel], st["y"], st["stats"])
+        meta = dict(kind="stem_fwd", layer=L.cb.conv_key, cout=L.c, flops=flops,
+                    bytes=float(x5.numel() * x5.element_size() + st["y"].pixels * L.c * esz))
+        if st["fwd_slot"] is None:
+            st["fwd_slot"] = len(pl.fwd)
+            pl.fwd.append(fwd, **meta)
+        else:
+            pl.fwd[st["fwd_slot"]] = fwd
+        if st.get("da") is not None:
+            bwd = self.be.stem_conv_wgrad(src, st["da"], self._gslice(L.w_off, L.w_numel))
+            if st["bwd_slot"] is None:
+                st["bwd_slot"] = len(pl.bwd)
+                pl.bwd.append(bwd, kind="stem_wgrad", layer=L.cb.conv_key, cout=L.c, flops=flops, bytes=meta["bytes"])
+                pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
+            else:
+                pl.bwd[st["bwd_slot"]] = bwd
+
     def _stem_fwd(self, pl, p: int, x5: torch.Tensor, t_index, out: FMap, train: bool):
         L = self._layers[self.wiring.stems[p].conv_key]
         g = L.cb.geom
@@ -405,23 +431,40 @@ class Engine:
         t_out = t_in if t_index is None else int(t_index.numel())
         ho = (h_in + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
         wo = (w_in + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
-        cols = self._fmap(f"cols.{p}", n, t_out, ho, wo, L.eg.cin)
-        pl.im2col_slots.append((len(pl.fwd), p))
-        pl.fwd.append(self.be.stem_im2col(Im2col(x5, t_index, g.k[1], g.k[2], (g.s[1], g.s[2]), (g.p[1], g.p[2]), cols)))
-        y, scale, shift, rec = self._unit_fwd(pl, L, cols, f"stem{p}", train, n)
+        tag = f"stem{p}"
+        y = self._fmap(f"y.{tag}", n, t_out, ho, wo, L.c)
+        scale = self._buf(f"scale.{tag}", L.c, torch.float32)
+        shift = self._buf(f"shift.{tag}", L.c, torch.float32)
+        gamma, beta = self._pslice(L.g_off, L.c), self._pslice(L.b_off, L.c)
+        st = {"y": y, "stats": None, "fwd_slot": None, "bwd_slot": None, "da": None}
+        pl.stem_state[p] = st
+        rec = None
+        if train:
+            mt = self.be.stem_conv_tiles(StemSrc(x5, t_index, g.k[0]), y)
+            st["stats"] = self._buf(f"stats.{tag}", mt * L.c * 2, torch.float32)
+            self._stem_ops(pl, p, x5, t_index)
+            mean = self._buf(f"mean.{tag}", L.c, torch.float32)
+            invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
+            pl.fwd.append(self.be.bn_finalize(st["stats"], mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
+                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift))
+            rec = _UnitRec(L, None, y, mean, invstd, scale, shift)
+        else:
+            self._stem_ops(pl, p, x5, t_index)
+            pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, L.rm, L.rv, self.spec.bn_eps, L.c, scale, shift))
         a = self._fmap(f"a.stem{p}", n, y.t, y.h, y.w, L.c)
         self._apply(pl, y, scale, shift, None, None, None, True, a)
         assert (out.h, out.w) == ((a.h + 2 - 3) // 2 + 1, (a.w + 2 - 3) // 2 + 1) and out.t == a.t
         argmax = self._buf(f"argmax.{p}", out.pixels * L.c, torch.uint8)
         pl.fwd.append(self.be.maxpool_fwd(a, out, argmax, 3, 2, 1))
-        return (rec, a, argmax, out)
+        return (rec, a, argmax, out, x5, t_index)
 
     def _stem_bwd(self, pl, p: int, srec, d_out: FMap):
-        rec, a, argmax, out = srec
+        rec, a, argmax, out, x5, t_index = srec
         da = self._fmap(f"da.stem{p}", a.n, a.t, a.h, a.w, a.c)
         pl.bwd.append(self.be.maxpool_bwd(d_out, argmax, da, 3, 2, 1))
         self._bn_bwd(pl, rec, da, f"stem{p}", True, None, False, da)
-        self._wgrad(pl, rec, da)
+        pl.stem_state[p]["da"] = da
+        self._stem_ops(pl, p, x5, t_index)
 
     # ---- lateral fusion: conv over the fast pathway -> BN -> ReLU -> channel slice of the slow buffer
     def _fusion_fwd(self, pl, bi: int, xf: FMap, out_slice: FMap, train: bool):
@@ -625,17 +668,8 @@ class Engine:
             pl.graph_epoch = 0
             self._plans[key] = pl
         elif pl.bound != ptrs():
-            for slot, p in pl.im2col_slots:
-                L = self._layers[self.wiring.stems[p].conv_key]
-                g = L.cb.geom
-                x5 = x_slow if p == 0 else x_fast
-                t_idx = slow_t_index if p == 0 else None
-                t_out = x5.shape[2] if t_idx is None else int(t_idx.numel())
-                ho = (x5.shape[3] + 2 * g.p[1] - g.k[1]) // g.s[1] + 1
-                wo = (x5.shape[4] + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
-                cols = self._fmap(f"cols.{p}", x5.shape[0], t_out, ho, wo, L.eg.cin)
-                pl.fwd[slot] = self.be.stem_im2col(Im2col(x5, t_idx, g.k[1], g.k[2], (g.s[1], g.s[2]),
-                                                          (g.p[1], g.p[2]), cols))
+            self._stem_ops(pl, 0, x_slow, slow_t_index)
+            self._stem_ops(pl, 1, x_fast, None)
             pl.bound = ptrs()
             pl.inputs = (x_slow, x_fast, slow_t_index)
             pl.graph_epoch += 1                          # a captured hipGraph of this plan is stale now
