@@ -27,6 +27,7 @@ struct ConvK {
   int cin, cout, wtaps, ntaps, KC, accumulate;
   int mtiles, ntiles;
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
+  uint32_t xbytes, wbytes;   // extents of the two buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, bool acc) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
   using TL = Tile<T>;
   constexpr int VEC = TL::VEC, SEGS = TL::SEGS, ROWB = TL::ROWB;
   constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
@@ -98,11 +99,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   constexpr int BUF = (BM + BN) * ROWB;
   static_assert(WM * WN == 4 && BM % RPI == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  __shared__ sfk_tap s_taps[SFK_MAX_TAPS + 1];   // + a sentinel that gathers nothing (K tail)
+  // per-tap tables (+ a sentinel entry that gathers nothing, for the ragged K tail)
+  __shared__ sfk_tap s_taps[SFK_MAX_TAPS + 1];
+  __shared__ int s_xdelta[SFK_MAX_TAPS + 1];   // element offset of the tap inside the input map
+  __shared__ int s_woff[SFK_MAX_TAPS + 1];     // widx * cin
   if (threadIdx.x <= SFK_MAX_TAPS) {
     sfk_tap t = k.taps[threadIdx.x < SFK_MAX_TAPS ? threadIdx.x : 0];
     if ((int)threadIdx.x >= k.ntaps) { t.dt = -128; t.dh = 0; t.dw = 0; t.widx = 0; }
     s_taps[threadIdx.x] = t;
+    s_xdelta[threadIdx.x] = (((int)t.dt * k.xh + (int)t.dh) * k.xw + (int)t.dw) * k.xld * (int)sizeof(T);   // bytes
+    s_woff[threadIdx.x] = (int)t.widx * k.cin * (int)sizeof(T);
   }
   __syncthreads();
 
@@ -120,9 +126,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
     mt = logical / k.ntiles;
   }
 
-  // ---- per-thread staging coordinates (fixed over the K loop)
+  // ---- per-thread staging coordinates (fixed over the K loop): pixel coordinates for the bounds test and the
+  // element offset of the un-shifted pixel; a tap only ADDS its table delta.
   const int seg = tid % SEGS, row0 = tid / SEGS;
-  int xn[XL], xtb[XL], xhb[XL], xwb[XL];
+  int xtb[XL], xhb[XL], xwb[XL];
+  uint32_t xbase[XL];   // byte offset of the un-shifted pixel inside the input buffer
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
     const int m = mt * BM + row0 + i * RPI;
@@ -130,51 +138,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
     k.drw.divmod((uint32_t)m, q1, rw_);
     k.drh.divmod(q1, q2, rh_);
     k.drt.divmod(q2, n_, rt_);
-    xn[i] = (int)n_;
     xtb[i] = (m < k.M) ? (int)rt_ * k.gst : -(1 << 28);  // rows past M gather nothing
     xhb[i] = (int)rh_ * k.gsh;
     xwb[i] = (int)rw_ * k.gsw;
+    xbase[i] = (uint32_t)((((((int64_t)n_ * k.xt + (int)rt_ * k.gst) * k.xh + xhb[i]) * k.xw + xwb[i]) * k.xld + k.xoff) *
+                          (int64_t)sizeof(T));
   }
-  const T* __restrict__ xp = static_cast<const T*>(k.x);
-  const T* __restrict__ wp = static_cast<const T*>(k.w);
+  uint32_t wbase[WL];
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    const int r = row0 + i * RPI;
+    const int co = nt * BN + r;
+    wbase[i] = (r < BN && co < k.cout) ? (uint32_t)(co * k.wtaps * k.cin) * (uint32_t)sizeof(T) : SFK_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
+  const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, k.wbytes);
 
   // K is the flattened (tap, channel) axis cut into 16-byte segments; a K-step takes SEGS consecutive segments, so
   // narrow layers (cin < 32) pack several taps into one MFMA step instead of padding each tap to 32 channels.
-  uint4 xr[XL], wr[WL];
-  const int spt = (int)k.dspt.d;
-  auto gload = [&](int step) {
+  // Loads are branch-free buffer loads: a slot that is conv padding / past the tile gets offset SFK_OOB and reads zeros.
+  struct Stage { uint4 x[XL]; uint4 w[WL]; };
+  auto gload = [&](int step, Stage& st) {
     const uint32_t q = (uint32_t)(step * SEGS + seg);
     uint32_t tap, cseg;
     k.dspt.divmod(q, tap, cseg);
-    const sfk_tap tp = s_taps[tap < (uint32_t)k.ntaps ? tap : SFK_MAX_TAPS];
     const bool cok = tap < (uint32_t)k.ntaps;
-    const int c = (int)cseg * VEC;
+    const int ti_ = cok ? (int)tap : SFK_MAX_TAPS;
+    const sfk_tap tp = s_taps[ti_];
+    const uint32_t xd = (uint32_t)(s_xdelta[ti_] + (int)cseg * 16);
+    const uint32_t wd = (uint32_t)(s_woff[ti_] + (int)cseg * 16);
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int ti = xtb[i] + tp.dt, hi = xhb[i] + tp.dh, wi = xwb[i] + tp.dw;
       const bool ok = cok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
                       (unsigned)wi < (unsigned)k.xw;
-      const int64_t off = ((((int64_t)xn[i] * k.xt + ti) * k.xh + hi) * k.xw + wi) * k.xld + k.xoff + c;
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(xp + off) : make_uint4(0, 0, 0, 0);
+      st.x[i] = sfk_buffer_load16(xrs, ok ? xbase[i] + xd : SFK_OOB);
     }
 #pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int r = row0 + i * RPI;
-      const int co = nt * BN + r;
-      const bool ok = cok && r < BN && co < k.cout;
-      const int64_t off = ((int64_t)co * k.wtaps + tp.widx) * k.cin + c;
-      wr[i] = ok ? *reinterpret_cast<const uint4*>(wp + off) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < WL; ++i)
+      st.w[i] = sfk_buffer_load16(wrs, (cok && wbase[i] != SFK_OOB) ? wbase[i] + wd : SFK_OOB);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const Stage& st) {
     char* xs = smem + buf * BUF;
     char* ws = xs + BM * ROWB;
 #pragma unroll
-    for (int i = 0; i < XL; ++i) *reinterpret_cast<uint4*>(xs + TL::off(row0 + i * RPI, seg)) = xr[i];
+    for (int i = 0; i < XL; ++i) *reinterpret_cast<uint4*>(xs + TL::off(row0 + i * RPI, seg)) = st.x[i];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       const int r = row0 + i * RPI;
-      if (r < BN) *reinterpret_cast<uint4*>(ws + TL::off(r, seg)) = wr[i];
+      if ((BN % RPI == 0) || r < BN) *reinterpret_cast<uint4*>(ws + TL::off(r, seg)) = st.w[i];
     }
   };
 
@@ -184,14 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nit = k.KC;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    const bool more = it + 1 < nit;
-    if (more) gload(it + 1);
+  auto compute = [&](int buf) {
     const char* xs = smem + buf * BUF;
     const char* ws = xs + BM * ROWB;
     typename TL::frag a[FN], b[FM];
@@ -203,7 +208,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j) TL::mma(acc[i][j], a[i], b[j]);
-    if (more) lstore(buf ^ 1);
+  };
+
+  // Software pipeline, two K-steps deep in registers: while step `it` runs on the matrix cores out of LDS buffer
+  // it&1, the tile of step it+1 waits in one register set and the loads of step it+2 are in flight in the other.
+  // K-steps past the end gather nothing (every slot is SFK_OOB -> zeros), so the body runs unconditionally for an even
+  // number of steps: no guards around the loads means the compiler counts them exactly (vmcnt(N), never a full drain).
+  const int nit2 = (k.KC + 1) & ~1;
+  Stage r0, r1;
+  gload(0, r0);
+  lstore(0, r0);
+  gload(1, r1);
+  __syncthreads();
+  for (int it = 0; it < nit2; it += 2) {
+    gload(it + 2, r0);
+    compute(0);
+    lstore(1, r1);
+    __syncthreads();
+    gload(it + 3, r1);
+    compute(1);
+    lstore(0, r0);
     __syncthreads();
   }
 
@@ -299,6 +323,10 @@ int validate(const sfk_conv_desc* d) {
   if (!sfk_fmap_vec_ok(&d->x)) return SFK_ERR_UNSUPPORTED;
   if ((d->y.c % 4) || (d->y.ld % 4) || (d->y.c_off % 4) || (((uintptr_t)d->y.ptr) & 15)) return SFK_ERR_UNSUPPORTED;
   if (((uintptr_t)d->w) & 15) return SFK_ERR_UNSUPPORTED;
+  // buffer resources address 32 bits
+  const int64_t esz = d->x.dtype == SFK_BF16 ? 2 : 4;
+  if (sfk_fmap_bytes(&d->x) >= (1ll << 32) - 64 || (int64_t)d->cout * d->wtaps * d->cin * esz >= (1ll << 32) - 64)
+    return SFK_ERR_UNSUPPORTED;
   return SFK_OK;
 }
 
@@ -318,6 +346,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dspt.set(d->cin / vec);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
+  k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
   const TileSel ts = pick_tile(d->cout);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;

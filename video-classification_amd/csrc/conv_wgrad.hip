@@ -26,6 +26,7 @@ struct WgradK {
   int citiles;                    // column tiles over the flattened (tap, cin) axis
   int chunks_per_split, nchunks;  // in stages of KS*32 pixels
   FastDiv dspt, dcin;             // 16-byte segments per tap; channels per tap
+  uint32_t xbytes, dbytes;        // extents of the buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -100,11 +101,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   const int stage1 = min(stage0 + k.chunks_per_split, k.nchunks);
   if (stage0 >= stage1) return;
 
-  const T* __restrict__ xp = static_cast<const T*>(k.x);
-  const T* __restrict__ dp = static_cast<const T*>(k.dy);
+  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
+  const __amdgpu_buffer_rsrc_t drs = sfk_make_rsrc(k.dy, k.dbytes);
 
   // column segment -> (tap, channel) of this thread's X slots (fixed for the whole kernel)
-  int xi_row[NLI], xi_soff[NLI], xi_c[NLI];
+  int xi_row[NLI], xi_soff[NLI], xi_cb[NLI];
   sfk_tap xi_tap[NLI];
   bool xi_ok[NLI];
 #pragma unroll
@@ -117,22 +118,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
     xi_tap[i] = s_taps[tap < (uint32_t)k.ntaps ? tap : SFK_MAX_TAPS];
     xi_row[i] = row;
     xi_soff[i] = row * ROWI + seg * 16;
-    xi_c[i] = (int)cseg * VEC;
+    xi_cb[i] = ((int)cseg * VEC + k.xoff) * (int)sizeof(T);
+  }
+  // dY slots: (row, channel segment) with the byte offset inside a pixel record
+  uint32_t di_off[NLO];
+#pragma unroll
+  for (int i = 0; i < NLO; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / SEGO, seg = idx % SEGO;
+    const int co = cot * TCO + seg * VEC;
+    di_off[i] = (idx < R * SEGO && co < k.cout) ? (uint32_t)((row * k.dld + k.doff + co) * (int)sizeof(T)) : SFK_OOB;
   }
   uint4 dr[NLO], xr[NLI];
+  // branch-free buffer loads: padding taps, rows past M and ragged channels read zeros through SFK_OOB
   auto gload = [&](int stage) {
+    const int m0 = stage * R;
+    const uint32_t rows_left = (uint32_t)(k.M - m0);       // stage <= nchunks-1 => > 0; past the end => huge -> all OOB below
 #pragma unroll
     for (int i = 0; i < NLO; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx / SEGO, seg = idx % SEGO;
-      const int m = stage * R + row;
-      const int co = cot * TCO + seg * VEC;
-      const bool ok = idx < R * SEGO && m < k.M && co < k.cout;
-      dr[i] = ok ? *reinterpret_cast<const uint4*>(dp + (int64_t)m * k.dld + k.doff + co) : make_uint4(0, 0, 0, 0);
+      const bool ok = di_off[i] != SFK_OOB && m0 < k.M && (uint32_t)(idx / SEGO) < rows_left;
+      dr[i] = sfk_buffer_load16(drs, ok ? (uint32_t)m0 * (uint32_t)(k.dld * (int)sizeof(T)) + di_off[i] : SFK_OOB);
     }
 #pragma unroll
     for (int i = 0; i < NLI; ++i) {
-      const int m = stage * R + xi_row[i];
+      const int m = m0 + xi_row[i];
       uint32_t q1, rw_, q2, rh_, n_, rt_;
       k.drw.divmod((uint32_t)m, q1, rw_);
       k.drh.divmod(q1, q2, rh_);
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
                 wi = (int)rw_ * k.gsw + xi_tap[i].dw;
       const bool ok = xi_ok[i] && m < k.M && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
                       (unsigned)wi < (unsigned)k.xw;
-      const int64_t off = ((((int64_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi) * k.xld + k.xoff + xi_c[i];
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(xp + off) : make_uint4(0, 0, 0, 0);
+      const uint32_t pix = (((uint32_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi;
+      xr[i] = sfk_buffer_load16(xrs, ok ? pix * (uint32_t)(k.xld * (int)sizeof(T)) + (uint32_t)xi_cb[i] : SFK_OOB);
     }
   };
   auto lstore = [&](int buf) {
@@ -169,8 +179,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   __syncthreads();
   for (int st = stage0; st < stage1; ++st) {
     const int buf = (st - stage0) & 1;
-    const bool more = st + 1 < stage1;
-    if (more) gload(st + 1);
+    gload(st + 1 < stage1 ? st + 1 : k.nchunks);   // past the end: every slot OOB (zeros), keeps the body branch-free
     const char* ds = smem + buf * BUF;
     const char* xs = ds + TILEO;
 #pragma unroll
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
 #pragma unroll
         for (int j = 0; j < FI; ++j) WO::mma(acc[i][j], a[i], b[j]);
     }
-    if (more) lstore(buf ^ 1);
+    lstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -222,6 +231,7 @@ int validate(const sfk_wgrad_desc* d) {
     if (d->gs[a] <= 0) return SFK_ERR_INVALID;
   if (sfk_fmap_pixels(&d->dy) >= (1ll << 31)) return SFK_ERR_UNSUPPORTED;
   if (!sfk_fmap_vec_ok(&d->x) || !sfk_fmap_vec_ok(&d->dy)) return SFK_ERR_UNSUPPORTED;
+  if (sfk_fmap_bytes(&d->x) >= (1ll << 32) - 64 || sfk_fmap_bytes(&d->dy) >= (1ll << 32) - 64) return SFK_ERR_UNSUPPORTED;
   return SFK_OK;
 }
 
@@ -258,6 +268,8 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s) {
   k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
   k.dspt.set(d->cin / sfk_vec_of(d->x.dtype));
   k.dcin.set(d->cin);
+  k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
+  k.dbytes = (uint32_t)sfk_fmap_bytes(&d->dy);
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
   const int cols = d->ntaps * d->cin;
   if (cols <= 32) {

@@ -35,6 +35,19 @@ struct FastDiv {
   }
 };
 
+// 128-bit buffer resource over [base, base+bytes): raw buffer loads with a per-lane BYTE offset; lanes whose offset is
+// >= bytes (we pass 0xFFFFFFFF for "this slot is conv padding / past the tile") read zeros -- no branch, no select,
+// and the compiler can count the loads exactly for s_waitcnt vmcnt(N).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sfk_make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 sfk_buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+constexpr uint32_t SFK_OOB = 0xFFFFFFFFu;
+
 template <typename T> struct DT;
 template <> struct DT<float> {
   static constexpr int code = SFK_F32;
@@ -76,3 +89,7 @@ static inline bool sfk_fmap_vec_ok(const sfk_fmap* f) {
   return (f->c % v) == 0 && (f->ld % v) == 0 && (f->c_off % v) == 0 && (((uintptr_t)f->ptr) & 15) == 0;
 }
 static inline int64_t sfk_fmap_pixels(const sfk_fmap* f) { return (int64_t)f->n * f->t * f->h * f->w; }
+// bytes from f->ptr to the end of the map's pixel records (the extent a buffer resource must cover)
+static inline int64_t sfk_fmap_bytes(const sfk_fmap* f) {
+  return sfk_fmap_pixels(f) * f->ld * (f->dtype == SFK_BF16 ? 2 : 4);
+}
