@@ -296,6 +296,226 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 production kernel: the same implicit GEMM with LDS-DMA staging (`buffer_load_dwordx4 ... lds`).
+//   * a wave-instruction writes 1 KiB = 16 tile rows x 64 B straight into LDS (dest = wave-uniform base + lane*16):
+//     lane l fills physical slot l&3 of row l>>2, and FETCHES the logical K segment (l&3) ^ f(row) -- the XOR
+//     swizzle of Tile<bf16>::off lives on the source side, the LDS image stays lane-linear (guide rule 21);
+//   * every lane has its own source offset, so the conv gather (taps, strides) costs nothing extra, and a lane whose
+//     pixel is padding / past the tile passes SFK_OOB: the buffer range check makes the DMA write ZEROS (verified on
+//     MI355X, tools/probe/ldsdma_oob.hip);
+//   * no staging VGPRs, no ds_write (the ~79 B/clk ds_write_b128 path was the LDS bottleneck of the register-staged
+//     loop); 3-slot LDS ring, DMA of step it+2 in flight while step it runs, one counted s_waitcnt vmcnt(N) + one raw
+//     s_barrier per K-step (never a full drain).
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
+  using T = bf16_t;
+  using TL = Tile<bf16_t>;
+  constexpr int VEC = 8, SEGS = 4, ROWB = 64;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  constexpr int WROWS = BN < 64 ? 64 : BN;     // every wave issues the same number of filter DMAs (rows >= BN are OOB)
+  constexpr int XI = BM / 64, WI = WROWS / 64; // DMA wave-instructions per wave per K-step
+  constexpr int BUF = (BM + WROWS) * ROWB;
+  constexpr int RED = WM * BN * 2 * 4;
+  constexpr int SM = 3 * BUF > RED ? 3 * BUF : RED;
+  constexpr int TAB = 32;   // ints per table
+  static_assert(WM * WN == 4, "tile shape");
+  // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt(0) before every fragment read): ring | tables
+  __shared__ __attribute__((aligned(16))) char smem[SM + 3 * TAB * 4];
+  sfk_tap* s_taps = reinterpret_cast<sfk_tap*>(smem + SM);
+  int* s_xdelta = reinterpret_cast<int*>(smem + SM) + TAB;
+  int* s_woff = reinterpret_cast<int*>(smem + SM) + 2 * TAB;
+  if (threadIdx.x <= SFK_MAX_TAPS) {
+    sfk_tap t = k.taps[threadIdx.x < SFK_MAX_TAPS ? threadIdx.x : 0];
+    if ((int)threadIdx.x >= k.ntaps) { t.dt = -128; t.dh = 0; t.dw = 0; t.widx = 0; }
+    s_taps[threadIdx.x] = t;
+    s_xdelta[threadIdx.x] = (((int)t.dt * k.xh + (int)t.dh) * k.xw + (int)t.dw) * k.xld * 2;
+    s_woff[threadIdx.x] = (int)t.widx * k.cin * 2;
+  }
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int l15 = lane & 15, g = lane >> 4;
+  int mt, nt;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    nt = logical % k.ntiles;
+    mt = logical / k.ntiles;
+  }
+
+  // this lane's tile rows: X rows wave*(BM/4) + 16j + (lane>>2), filter rows wave*(WROWS/4) + 16j + (lane>>2);
+  // rows 16 apart share (row>>2)&3, so ONE logical segment per lane
+  const int lrow = lane >> 2;
+  const int seg = (lane & 3) ^ ((4 - (((wave * (BM / 4) + lrow) >> 2) & 3)) & 3);
+  static_assert((BM / 4) % 16 == 0 && (WROWS / 4) % 16 == 0, "row blocks");
+  int xtb[XI], xhb[XI], xwb[XI];
+  uint32_t xbase[XI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const int m = mt * BM + wave * (BM / 4) + 16 * j + lrow;
+    uint32_t q1, rw_, q2, rh_, n_, rt_;
+    k.drw.divmod((uint32_t)m, q1, rw_);
+    k.drh.divmod(q1, q2, rh_);
+    k.drt.divmod(q2, n_, rt_);
+    xtb[j] = (m < k.M) ? (int)rt_ * k.gst : -(1 << 28);
+    xhb[j] = (int)rh_ * k.gsh;
+    xwb[j] = (int)rw_ * k.gsw;
+    xbase[j] = (uint32_t)((((((int64_t)n_ * k.xt + (int)rt_ * k.gst) * k.xh + xhb[j]) * k.xw + xwb[j]) * k.xld + k.xoff) * 2);
+  }
+  // the filter tile uses the same swizzle function on ITS row index
+  const int wseg = (lane & 3) ^ ((4 - (((wave * (WROWS / 4) + lrow) >> 2) & 3)) & 3);
+  uint32_t wbase[WI];
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int r = wave * (WROWS / 4) + 16 * j + lrow;
+    const int co = nt * BN + r;
+    wbase[j] = (r < BN && co < k.cout) ? (uint32_t)(co * k.wtaps * k.cin) * 2u : SFK_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
+  const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, k.wbytes);
+
+  auto dma = [&](int step, int buf) {
+    char* xs = smem + buf * BUF + wave * (BM / 4) * ROWB;
+    char* ws = smem + buf * BUF + BM * ROWB + wave * (WROWS / 4) * ROWB;
+    {
+      uint32_t tap, cseg;
+      k.dspt.divmod((uint32_t)(step * SEGS + seg), tap, cseg);
+      const bool cok = tap < (uint32_t)k.ntaps;
+      const int ti_ = cok ? (int)tap : SFK_MAX_TAPS;
+      const sfk_tap tp = s_taps[ti_];
+      const uint32_t xd = (uint32_t)(s_xdelta[ti_] + (int)cseg * 16);
+#pragma unroll
+      for (int j = 0; j < XI; ++j) {
+        const int ti = xtb[j] + tp.dt, hi = xhb[j] + tp.dh, wi = xwb[j] + tp.dw;
+        const bool ok = cok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
+                        (unsigned)wi < (unsigned)k.xw;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + 16 * j * ROWB), 16, (int)(ok ? xbase[j] + xd : SFK_OOB), 0, 0, 0);
+      }
+    }
+    {
+      uint32_t tap, cseg;
+      k.dspt.divmod((uint32_t)(step * SEGS + wseg), tap, cseg);
+      const bool cok = tap < (uint32_t)k.ntaps;
+      const uint32_t wd = (uint32_t)(s_woff[cok ? (int)tap : SFK_MAX_TAPS] + (int)cseg * 16);
+#pragma unroll
+      for (int j = 0; j < WI; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(ws + 16 * j * ROWB), 16,
+                                                 (int)((cok && wbase[j] != SFK_OOB) ? wbase[j] + wd : SFK_OOB), 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* xs = smem + buf * BUF;
+    const char* ws = xs + BM * ROWB;
+    TL::frag a[FN], b[FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) a[i] = TL::load(ws, wn * (BN / WN) + 16 * i + l15, g);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) b[j] = TL::load(xs, wm * (BM / WM) + 16 * j + l15, g);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) TL::mma(acc[i][j], a[i], b[j]);
+  };
+
+  // 3-slot ring.  Invariant at the top of iteration `it`: slot it%3 has landed for every wave (barrier), the DMAs of
+  // step it+1 are in flight.  Issue step it+2 into the slot that step it-1 vacated, run step it, then wait until only
+  // this wave's XI+WI newest DMAs (step it+2) are outstanding and meet the other waves.
+  dma(0, 0);
+  dma(1, 1);
+  if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt2 = 2;
+  for (int it = 0; it < k.KC; ++it) {
+    dma(it + 2, nxt2);
+    compute(cur);
+    if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-OOB) tail DMAs before LDS is reused / the block ends
+  __syncthreads();
+
+  // ---- epilogue (identical to the register-staged kernel)
+  T* __restrict__ yp = static_cast<T*>(k.y);
+  const int co_w = nt * BN + wn * (BN / WN);
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (m < k.M) {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int co = co_w + 16 * i + 4 * g;
+        if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+      }
+    }
+  }
+  if (k.stats) {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) {
+          s1 += __shfl_xor(s1, sft);
+          s2 += __shfl_xor(s2, sft);
+        }
+        if (l15 == 0) {
+          const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < k.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) {
+          s1 += red[(w_ * BN + tid) * 2 + 0];
+          s2 += red[(w_ * BN + tid) * 2 + 1];
+        }
+        float* o = k.stats + ((int64_t)mt * k.cout + co) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+    }
+  }
+}
+
 struct TileSel { int bm, bn; };
 inline TileSel pick_tile(int cout) {
   if (cout > 64) return {128, 128};
@@ -330,6 +550,16 @@ int validate(const sfk_conv_desc* d) {
   return SFK_OK;
 }
 
+int launch_dma(const ConvK& k, int bn, dim3 grid, hipStream_t s) {
+  const dim3 block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), grid, block, 0, s, k);
+  else if (bn == 64) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 64, 4, 1>), grid, block, 0, s, k);
+  else if (bn == 32) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 32, 4, 1>), grid, block, 0, s, k);
+  else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 16, 4, 1>), grid, block, 0, s, k);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
 template <typename T>
 int launch(const sfk_conv_desc* d, hipStream_t s) {
   ConvK k;
@@ -353,6 +583,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
   const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
+  // bf16: LDS-DMA ring for the wide tile; narrow outputs keep the register-staged kernel (higher occupancy, tiny K)
+  if (sizeof(T) == 2 && ts.bn == 128) return launch_dma(k, ts.bn, grid, s);
   if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, k);
   else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1>), grid, block, 0, s, k);
   else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1>), grid, block, 0, s, k);
