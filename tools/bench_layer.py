@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Micro-benchmark of ONE conv layer of the metric model through the C ABI (for rocprofv3 --pmc runs).
+usage: python tools/bench_layer.py <kind> [reps]   kind in fwd_a4, fwd_b4, fwd_c4, wgrad_a4, wgrad_b4, dgrad_a4, fwd_c2"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_classification_amd._lib import ConvPass, FMap, HipBackend, WgradPass
+from video_classification_amd.plan import ConvGeom, dgrad_passes, fwd_pass, wgrad_taps
+
+LAYERS = {  # cin, cout, k, s, p, (t, h, w)     batch 32
+    "a4": (1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (8, 14, 14)),
+    "b4": (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 14, 14)),
+    "c4": (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 14, 14)),
+    "c2": (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)),
+    "b2": (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 56, 56)),
+}
+kind = sys.argv[1] if len(sys.argv) > 1 else "fwd_a4"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+op, name = kind.split("_")
+cin, cout, k, s, p, dims = LAYERS[name]
+n = 32
+be = HipBackend()
+dev = "cuda"
+g = ConvGeom(cin, cout, k, s, p)
+od = g.out_dims(dims)
+x = FMap(torch.randn(n * dims[0] * dims[1] * dims[2] * cin, device=dev).bfloat16(), n, *dims, cin)
+y = FMap(torch.randn(n * od[0] * od[1] * od[2] * cout, device=dev).bfloat16(), n, *od, cout)
+w = (torch.randn(cout * g.wtaps * cin, device=dev) * (g.wtaps * cin) ** -0.5).bfloat16()
+runs = []
+if op == "fwd":
+    sp = fwd_pass(g, dims)
+    ps = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cin, cout)
+    mt = be.conv_igemm_mtiles(ps)
+    ps.stats = torch.zeros(mt * cout * 2, device=dev)
+    runs = [be.conv_igemm(ps)]
+elif op == "dgrad":
+    for sp in dgrad_passes(g, dims)[0]:
+        runs.append(be.conv_igemm(ConvPass(y, x, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cout, cin)))
+else:
+    dw = torch.zeros(cout * g.wtaps * cin, device=dev)
+    runs = [be.conv_wgrad(WgradPass(x, y, g.s, list(wgrad_taps(g)), dw, g.wtaps, cin, cout))]
+st = torch.cuda.current_stream().cuda_stream
+for r in runs: r(st)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(reps):
+    for r in runs: r(st)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / reps
+fl = 2.0 * n * od[0] * od[1] * od[2] * cout * cin * g.wtaps
+print(f"{kind}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")

@@ -310,18 +310,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
   constexpr int VEC = 8, SEGS = 4, ROWB = 64;
   constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-  constexpr int WROWS = BN < 64 ? 64 : BN;     // every wave issues the same number of filter DMAs (rows >= BN are OOB)
-  constexpr int XI = BM / 64, WI = WROWS / 64; // DMA wave-instructions per wave per K-step
+  constexpr int NW = WM * WN;                  // waves per block (4 or 8)
+  constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;   // every wave issues the same number of filter DMAs (rows >= BN are OOB)
+  constexpr int XI = BM / (16 * NW), WI = WROWS / (16 * NW);   // DMA wave-instructions per wave per K-step
   constexpr int BUF = (BM + WROWS) * ROWB;
   constexpr int RED = WM * BN * 2 * 4;
   constexpr int SM = 3 * BUF > RED ? 3 * BUF : RED;
   constexpr int TAB = 32;   // ints per table
-  static_assert(WM * WN == 4, "tile shape");
+  static_assert((NW == 4 || NW == 8) && BM % (16 * NW) == 0, "tile shape");
   // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt(0) before every fragment read): ring | tables
   __shared__ __attribute__((aligned(16))) char smem[SM + 3 * TAB * 4];
   sfk_tap* s_taps = reinterpret_cast<sfk_tap*>(smem + SM);
@@ -352,13 +353,13 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
   // this lane's tile rows: X rows wave*(BM/4) + 16j + (lane>>2), filter rows wave*(WROWS/4) + 16j + (lane>>2);
   // rows 16 apart share (row>>2)&3, so ONE logical segment per lane
   const int lrow = lane >> 2;
-  const int seg = (lane & 3) ^ ((4 - (((wave * (BM / 4) + lrow) >> 2) & 3)) & 3);
-  static_assert((BM / 4) % 16 == 0 && (WROWS / 4) % 16 == 0, "row blocks");
+  const int seg = (lane & 3) ^ ((4 - (((wave * (BM / NW) + lrow) >> 2) & 3)) & 3);
+  static_assert((BM / NW) % 16 == 0 && (WROWS / NW) % 16 == 0, "row blocks");
   int xtb[XI], xhb[XI], xwb[XI];
   uint32_t xbase[XI];
 #pragma unroll
   for (int j = 0; j < XI; ++j) {
-    const int m = mt * BM + wave * (BM / 4) + 16 * j + lrow;
+    const int m = mt * BM + wave * (BM / NW) + 16 * j + lrow;
     uint32_t q1, rw_, q2, rh_, n_, rt_;
     k.drw.divmod((uint32_t)m, q1, rw_);
     k.drh.divmod(q1, q2, rh_);
@@ -369,44 +370,80 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
     xbase[j] = (uint32_t)((((((int64_t)n_ * k.xt + (int)rt_ * k.gst) * k.xh + xhb[j]) * k.xw + xwb[j]) * k.xld + k.xoff) * 2);
   }
   // the filter tile uses the same swizzle function on ITS row index
-  const int wseg = (lane & 3) ^ ((4 - (((wave * (WROWS / 4) + lrow) >> 2) & 3)) & 3);
+  const int wseg = (lane & 3) ^ ((4 - (((wave * (WROWS / NW) + lrow) >> 2) & 3)) & 3);
   uint32_t wbase[WI];
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
-    const int r = wave * (WROWS / 4) + 16 * j + lrow;
+    const int r = wave * (WROWS / NW) + 16 * j + lrow;
     const int co = nt * BN + r;
     wbase[j] = (r < BN && co < k.cout) ? (uint32_t)(co * k.wtaps * k.cin) * 2u : SFK_OOB;
   }
   const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
   const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, k.wbytes);
 
-  auto dma = [&](int step, int buf) {
-    char* xs = smem + buf * BUF + wave * (BM / 4) * ROWB;
-    char* ws = smem + buf * BUF + BM * ROWB + wave * (WROWS / 4) * ROWB;
-    {
+  // Two ways to walk K.  uniform (cin % 32 == 0): a K-step stays inside ONE tap; the per-lane offsets (gather +
+  // bounds test) are recomputed only when the tap changes and the channel-chunk advance (kc * 64 B) is wave-uniform,
+  // so it rides the buffer instruction's SGPR soffset -- zero per-step VALU.  packed (narrow / ragged cin): segments
+  // of one step may belong to different taps, offsets are rebuilt per step.
+  const bool uniform = (k.cin & 31) == 0;
+  const int kct = k.cin >> 5;                       // K-steps per tap (uniform mode)
+  constexpr uint32_t FAR = 0x80000000u;             // stays out of range after adding any soffset (extents < 2 GiB)
+  uint32_t xv[XI], wv[WI];                          // current voffsets (uniform mode)
+  int u_tap = 0, u_kc = 0, p_step = 0;
+
+  auto issue = [&](int buf, const uint32_t (&xo)[XI], const uint32_t (&wo)[WI], int soff) {
+    char* xs = smem + buf * BUF + wave * (BM / NW) * ROWB;
+    char* ws = smem + buf * BUF + BM * ROWB + wave * (WROWS / NW) * ROWB;
+#pragma unroll
+    for (int j = 0; j < XI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + 16 * j * ROWB), 16, (int)xo[j], soff, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(ws + 16 * j * ROWB), 16, (int)wo[j], soff, 0, 0);
+  };
+  auto dma = [&](int buf) {
+    if (uniform) {
+      if (u_kc == 0) {                               // entering tap u_tap (wave-uniform branch)
+        if (u_tap < k.ntaps) {
+          const sfk_tap tp = s_taps[u_tap];
+          const int xd = s_xdelta[u_tap] + seg * 16;
+          const int wd = s_woff[u_tap] + seg * 16;
+#pragma unroll
+          for (int j = 0; j < XI; ++j) {
+            const int ti = xtb[j] + tp.dt, hi = xhb[j] + tp.dh, wi = xwb[j] + tp.dw;
+            const bool ok = (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh && (unsigned)wi < (unsigned)k.xw;
+            xv[j] = ok ? xbase[j] + (uint32_t)xd : FAR;
+          }
+#pragma unroll
+          for (int j = 0; j < WI; ++j) wv[j] = wbase[j] != SFK_OOB ? wbase[j] + (uint32_t)wd : FAR;
+        } else {                                     // past the last tap: the ring's look-ahead gathers nothing
+#pragma unroll
+          for (int j = 0; j < XI; ++j) xv[j] = FAR;
+#pragma unroll
+          for (int j = 0; j < WI; ++j) wv[j] = FAR;
+        }
+      }
+      issue(buf, xv, wv, u_kc * 64);
+      if (++u_kc == kct) { u_kc = 0; ++u_tap; }
+    } else {
+      uint32_t xo[XI], wo[WI];
       uint32_t tap, cseg;
-      k.dspt.divmod((uint32_t)(step * SEGS + seg), tap, cseg);
+      k.dspt.divmod((uint32_t)(p_step * SEGS + seg), tap, cseg);
       const bool cok = tap < (uint32_t)k.ntaps;
       const int ti_ = cok ? (int)tap : SFK_MAX_TAPS;
       const sfk_tap tp = s_taps[ti_];
       const uint32_t xd = (uint32_t)(s_xdelta[ti_] + (int)cseg * 16);
+      const uint32_t wd = (uint32_t)(s_woff[ti_] + (int)cseg * 16);
 #pragma unroll
       for (int j = 0; j < XI; ++j) {
         const int ti = xtb[j] + tp.dt, hi = xhb[j] + tp.dh, wi = xwb[j] + tp.dw;
-        const bool ok = cok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
-                        (unsigned)wi < (unsigned)k.xw;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + 16 * j * ROWB), 16, (int)(ok ? xbase[j] + xd : SFK_OOB), 0, 0, 0);
+        const bool ok = cok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh && (unsigned)wi < (unsigned)k.xw;
+        xo[j] = ok ? xbase[j] + xd : FAR;
       }
-    }
-    {
-      uint32_t tap, cseg;
-      k.dspt.divmod((uint32_t)(step * SEGS + wseg), tap, cseg);
-      const bool cok = tap < (uint32_t)k.ntaps;
-      const uint32_t wd = (uint32_t)(s_woff[cok ? (int)tap : SFK_MAX_TAPS] + (int)cseg * 16);
 #pragma unroll
-      for (int j = 0; j < WI; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(ws + 16 * j * ROWB), 16,
-                                                 (int)((cok && wbase[j] != SFK_OOB) ? wbase[j] + wd : SFK_OOB), 0, 0, 0);
+      for (int j = 0; j < WI; ++j) wo[j] = (cok && wbase[j] != SFK_OOB) ? wbase[j] + wd : FAR;
+      issue(buf, xo, wo, 0);
+      ++p_step;
     }
   };
 
@@ -416,41 +453,48 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf) {
-    const char* xs = smem + buf * BUF;
-    const char* ws = xs + BM * ROWB;
+  // fragment addresses inside a ring slot are loop-invariant; the slot base is a compile-time constant (ring unrolled)
+  int a_off[FN], b_off[FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) a_off[i] = BM * ROWB + TL::off(wn * (BN / WN) + 16 * i + l15, g);
+#pragma unroll
+  for (int j = 0; j < FM; ++j) b_off[j] = TL::off(wm * (BM / WM) + 16 * j + l15, g);
+  auto compute = [&](int slot_base) {
     TL::frag a[FN], b[FM];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) a[i] = TL::load(ws, wn * (BN / WN) + 16 * i + l15, g);
+    for (int i = 0; i < FN; ++i) a[i] = *reinterpret_cast<const TL::frag*>(smem + slot_base + a_off[i]);
 #pragma unroll
-    for (int j = 0; j < FM; ++j) b[j] = TL::load(xs, wm * (BM / WM) + 16 * j + l15, g);
+    for (int j = 0; j < FM; ++j) b[j] = *reinterpret_cast<const TL::frag*>(smem + slot_base + b_off[j]);
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j) TL::mma(acc[i][j], a[i], b[j]);
   };
-
-  // 3-slot ring.  Invariant at the top of iteration `it`: slot it%3 has landed for every wave (barrier), the DMAs of
-  // step it+1 are in flight.  Issue step it+2 into the slot that step it-1 vacated, run step it, then wait until only
-  // this wave's XI+WI newest DMAs (step it+2) are outstanding and meet the other waves.
-  dma(0, 0);
-  dma(1, 1);
-  if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int cur = 0, nxt2 = 2;
-  for (int it = 0; it < k.KC; ++it) {
-    dma(it + 2, nxt2);
-    compute(cur);
-    if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  auto ring_wait = [&]() {
+    static_assert(XI + WI >= 2 && XI + WI <= 5, "DMA count");
+    if constexpr (XI + WI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+  };
+
+  // 3-slot ring, unrolled so that slot addresses are immediates.  Invariant at the top of a sub-step that computes
+  // slot c: c has landed for every wave (barrier); the DMAs of the next step are in flight.  Issue the step after
+  // next into the slot the previous step vacated, run this step, wait until only this wave's newest XI+WI DMAs are
+  // outstanding, meet the other waves.
+  dma(0);
+  dma(1);
+  ring_wait();
+  for (int it = 0;;) {
+    dma(2); compute(0 * BUF); ring_wait();
+    if (++it >= k.KC) break;
+    dma(0); compute(1 * BUF); ring_wait();
+    if (++it >= k.KC) break;
+    dma(1); compute(2 * BUF); ring_wait();
+    if (++it >= k.KC) break;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-OOB) tail DMAs before LDS is reused / the block ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-out-of-range) look-ahead DMAs before LDS is reused
   __syncthreads();
 
   // ---- epilogue (identical to the register-staged kernel)
@@ -517,7 +561,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma_kernel(const ConvK k) {
 }
 
 struct TileSel { int bm, bn; };
-inline TileSel pick_tile(int cout) {
+inline TileSel pick_tile(int cout, int dtype, int64_t M) {
+  // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
+  // once the grid still fills the chip
+  if (cout > 64 && dtype == SFK_BF16 && M >= 256 * 128) return {256, 128};
   if (cout > 64) return {128, 128};
   if (cout > 32) return {256, 64};
   if (cout > 16) return {256, 32};
@@ -550,12 +597,9 @@ int validate(const sfk_conv_desc* d) {
   return SFK_OK;
 }
 
-int launch_dma(const ConvK& k, int bn, dim3 grid, hipStream_t s) {
-  const dim3 block(256);
-  if (bn == 128) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), grid, block, 0, s, k);
-  else if (bn == 64) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 64, 4, 1>), grid, block, 0, s, k);
-  else if (bn == 32) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 32, 4, 1>), grid, block, 0, s, k);
-  else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 16, 4, 1>), grid, block, 0, s, k);
+int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
+  if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2>), grid, dim3(512), 0, s, k);
+  else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, k);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -579,12 +623,15 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  const TileSel ts = pick_tile(d->cout);
+  const TileSel ts = pick_tile(d->cout, d->x.dtype, k.M);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
   const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
   // bf16: LDS-DMA ring for the wide tile; narrow outputs keep the register-staged kernel (higher occupancy, tiny K)
-  if (sizeof(T) == 2 && ts.bn == 128) return launch_dma(k, ts.bn, grid, s);
+  if (sizeof(T) == 2 && ts.bn == 128) {
+    if (k.xbytes < 0x7FF00000u && k.wbytes < 0x7FF00000u) return launch_dma(k, ts.bm, grid, s);
+    return SFK_ERR_UNSUPPORTED;   // the DMA path addresses < 2 GiB per operand
+  }
   if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, k);
   else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1>), grid, block, 0, s, k);
   else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1>), grid, block, 0, s, k);
@@ -599,7 +646,8 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int st = validate(d);
   if (st != SFK_OK) return st;
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
-  return (int)((M + pick_tile(d->cout).bm - 1) / pick_tile(d->cout).bm);
+  const int bm = pick_tile(d->cout, d->x.dtype, M).bm;
+  return (int)((M + bm - 1) / bm);
 }
 
 extern "C" int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream) {
