@@ -52,6 +52,9 @@ CONV_CASES = [
     (8, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (2, 16, 6, 5)),     # canonical lateral fusion
     (160, 8, (5, 1, 1), (1, 1, 1), (2, 0, 0), (1, 8, 6, 6)),     # fast stem temporal part over the patch matrix
     (8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1, 1)),       # a single pixel
+    (64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 64, 66)),  # M = 33792 rows: the 256x128 LDS-DMA tile, uniform-K walk
+    (80, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 8, 72, 60)),  # M = 34560, cin = 2.5 K-steps: 256x128 tile, packed-K walk
+    (128, 96, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 20, 22)),  # 128x128 LDS-DMA tile, 9 taps, stride 2, ragged cout
 ]
 
 

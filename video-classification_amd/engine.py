@@ -58,16 +58,35 @@ class _UnitRec:
     shift: torch.Tensor
 
 
+class Wait:
+    """Schedule marker: stream of pathway `lane` must wait for everything issued so far on pathway `on`.
+    A no-op when the schedule runs on a single stream (stream order already implies it)."""
+
+    def __init__(self, lane: int, on: int):
+        self.lane, self.on = lane, on
+
+    def __call__(self, stream):
+        return None
+
+
 class OpList(list):
-    """A kernel schedule; `meta[i]` describes op i for the profiler / roofline report (None for glue ops)."""
+    """A kernel schedule; `meta[i]` describes op i for the profiler / roofline report (None for glue ops), `lane[i]`
+    is the pathway stream it belongs to (0 = slow pathway / trunk, 1 = fast pathway).  The two pathways only meet at the
+    lateral fusions, so their kernels run concurrently on two HIP streams (inside one hipGraph when captured)."""
 
     def __init__(self):
         super().__init__()
         self.meta: List[Optional[dict]] = []
+        self.lane: List[int] = []
+        self.cur_lane = 0
 
     def append(self, op, **meta):
         super().append(op)
         self.meta.append(meta or None)
+        self.lane.append(op.lane if isinstance(op, Wait) else self.cur_lane)
+
+    def sync(self, lane: int, on: int):
+        self.append(Wait(lane, on))
 
 
 class Plan:
@@ -112,6 +131,8 @@ class Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._plans: Dict[tuple, Plan] = {}
         self._build_params(seed)
+        self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
+        self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------ parameters
@@ -565,17 +586,24 @@ class Engine:
 
         cat0, s0 = slow_buffer("cat.0", ts, hs, ws, c_s, 0)
         xf = self._fmap("xf.0", n, tf, hf, wf, c_f)
-        stem_recs = [self._stem_fwd(pl, 0, x_slow, slow_t_index, s0, train),
-                     self._stem_fwd(pl, 1, x_fast, None, xf, train)]
+        F_, B_ = pl.fwd, pl.bwd
+        F_.sync(1, 0)                                   # fork: the fast pathway starts after the filter refresh
+        F_.cur_lane = 0
+        srec0 = self._stem_fwd(pl, 0, x_slow, slow_t_index, s0, train)
+        F_.cur_lane = 1
+        srec1 = self._stem_fwd(pl, 1, x_fast, None, xf, train)
+        stem_recs = [srec0, srec1]
         fusion_recs = [None] * 4
         if fuse:
             fusion_recs[0] = self._fusion_fwd(pl, 0, xf, cat0.channels(c_s, cat0.c - c_s), train)
+            F_.sync(0, 1)                               # the slow pathway reads the fused channels
         xs_full = cat0
         stage_recs = []
         xs_fulls, xfs = [cat0], [xf]
         for si in range(4):
             recs_sp = []
             for p in range(2):
+                F_.cur_lane = p
                 blocks = W.stages[si][p]
                 x = xs_full if p == 0 else xf
                 brecs = []
@@ -598,12 +626,16 @@ class Engine:
             xs_full = xs_full_next
             c_slow = W.stages[si][0][-1].conv_c.geom.cout
             if fuse and si < 3:
+                F_.cur_lane = 1
                 fusion_recs[si + 1] = self._fusion_fwd(pl, si + 1, xf, xs_full.channels(c_slow, xs_full.c - c_slow),
                                                        train)
+                F_.sync(0, 1)
             stage_recs.append(recs_sp)
             xs_fulls.append(xs_full)
             xfs.append(xf)
-        # ---- head
+        # ---- head (trunk stream; joins the fast pathway)
+        F_.sync(0, 1)
+        F_.cur_lane = 0
         xs_out, xf_out = xs_full, xf
         F = self.fc_in
         feat = self._buf("feat", n * F, torch.float32)
@@ -629,22 +661,30 @@ class Engine:
         d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
         pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
         pl.bwd.append(be.head_pool_bwd(dfeat, F, xs_out.c, kf, rate, self.drop_seed, d_xf))
+        B_.sync(1, 0)                                   # fork
         for si in range(3, -1, -1):
             # slow pathway of this stage: d_xs is the gradient of its last block's output
+            B_.cur_lane = 0
             d = d_xs
             for brec in reversed(stage_recs[si][0]):
                 d = self._block_bwd(pl, brec, d)
             d_cat = d                                   # gradient of the (concatenated) slow input of this stage
+            B_.cur_lane = 1
             d = d_xf
             for brec in reversed(stage_recs[si][1]):
                 d = self._block_bwd(pl, brec, d)
             d_xf = d
             c_prev = xs_fulls[si].c - (W.fusions[si].geom.cout if fuse else 0)
             if fuse:
+                B_.sync(1, 0)                           # the fusion's gradient comes out of the slow pathway's d_cat
                 self._fusion_bwd(pl, si, fusion_recs[si], d_cat.channels(c_prev, d_cat.c - c_prev), d_xf)
             d_xs = d_cat.channels(0, c_prev)
+        B_.cur_lane = 0
         self._stem_bwd(pl, 0, stem_recs[0], d_xs)
+        B_.cur_lane = 1
         self._stem_bwd(pl, 1, stem_recs[1], d_xf)
+        B_.sync(0, 1)                                   # join before the optimiser
+        B_.cur_lane = 0
         return pl
 
     # ------------------------------------------------------------------ execution
@@ -685,6 +725,24 @@ class Engine:
         for op in ops:
             op(stream)
 
+    def _run_lanes(self, ops: "OpList"):
+        """Run a schedule on two streams: pathway 0 on the current stream, pathway 1 on a side stream, ordered by
+        the Wait markers (events).  Capturable: the side stream forks from / joins into the capturing stream."""
+        if self.device.type != "cuda" or not self.two_streams:
+            return self._run(ops, self._stream())
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        streams = (main, self._side)
+        handles = (main.cuda_stream, self._side.cuda_stream)
+        for op, lane in zip(ops, ops.lane):
+            if isinstance(op, Wait):
+                ev = torch.cuda.Event()
+                ev.record(streams[op.on])
+                streams[op.lane].wait_event(ev)
+            else:
+                op(handles[lane])
+
     def forward(self, x_slow: torch.Tensor, x_fast: torch.Tensor, train: bool, slow_t_index=None) -> Plan:
         """x_*: (N, C, T, H, W) views with ANY strides (the dataset's N,T,C,H,W memory is read in place).
         If slow_t_index is given, the slow pathway reads frames x_slow[:, :, slow_t_index] (PackPathway)."""
@@ -693,7 +751,7 @@ class Engine:
         pl = self._plan_for(x_slow, x_fast, slow_t_index, train)
         if train:
             self.drop_seed.add_(1)
-        self._run(pl.fwd, self._stream())
+        self._run_lanes(pl.fwd)
         return pl
 
     def backward(self, pl: Plan, dlogits: Optional[torch.Tensor] = None, zero_grad: bool = True):
@@ -702,7 +760,7 @@ class Engine:
             pl.dlogits.copy_(dlogits)
         if zero_grad:
             self.G.zero_()
-        self._run(pl.bwd, self._stream())
+        self._run_lanes(pl.bwd)
 
     # ---- fused loss + optimiser (train.py:228-231 without the per-step .item() sync of :236)
     def loss_ops(self, pl: Plan, labels: torch.Tensor, loss_out, loss_sum, correct, gscale: float = 1.0) -> Run:

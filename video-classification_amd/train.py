@@ -64,12 +64,12 @@ class TrainStep:
         eng = self.eng
         st = eng._stream()
         eng.drop_seed.add_(1)
-        eng._run(pl.fwd, st)
+        eng._run_lanes(pl.fwd)
         ops["zero_loss"](st)
         ops["loss"](st)
         ops["zero_grad"](st)
         if self.world == 1:
-            eng._run(pl.bwd, st)
+            eng._run_lanes(pl.bwd)
         else:
             self.reducer.begin()
             for a, b, ranges in pl.grad_segments(self.overlap_segments):
