@@ -219,6 +219,210 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 production kernel for wide layers: the same GEMM with LDS-DMA staging (see conv_igemm.hip for the scheme).
+//   * tiles [32 pixels][TC channels] are written by `buffer_load_dwordx4 ... lds`; a wave-instruction covers 1 KiB =
+//     4 rows of 256 B (TC = 128) or 2 rows of 512 B (TC = 256); lane l fills physical 16-B slot l % (L/16) of its row
+//     and FETCHES logical slot  phys ^ f(row),  f(row) = ((row&3) | ((row>>3)&1)<<2) << 1 : the 8 rows a
+//     ds_read_b64_tr_b16 half-wave touches then land on 8 disjoint 32-B bank windows (unswizzled: 8-way conflict);
+//   * dY, and X of pointwise stride-1 convs, advance by a wave-uniform byte count per stage -> SGPR soffset, zero VALU;
+//     gathered X (taps / strides) rebuilds its per-lane offsets per stage (each lane's column = one fixed tap);
+//   * 3-slot ring, counted vmcnt, one raw barrier per 32-pixel stage; fp32 atomics epilogue as the generic kernel.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+template <int TCO, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_kernel(const WgradK k) {
+  constexpr int TCI = 128, R = MK;
+  constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
+  constexpr int SO = LO / 16, SI = LI / 16;                 // 16-byte slots per row
+  constexpr int NDO = R * LO / 1024 / NW, NDI = R * LI / 1024 / NW;   // DMA instructions per wave per stage
+  constexpr int TILEO = R * LO, TILEI = R * LI, BUF = TILEO + TILEI;
+  constexpr int WCO = TCO / 64;                             // waves along co (each wave 64 co x 64 columns)
+  static_assert(NW == WCO * 2 && NDO >= 1 && NDI >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave % WCO, wci = wave / WCO;
+  const int cot = blockIdx.x / k.citiles, cit = blockIdx.x % k.citiles;
+  const int stage0 = blockIdx.z * k.chunks_per_split;
+  const int stage1 = min(stage0 + k.chunks_per_split, k.nchunks);
+  if (stage0 >= stage1) return;
+  constexpr uint32_t FAR = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
+  const __amdgpu_buffer_rsrc_t drs = sfk_make_rsrc(k.dy, k.dbytes);
+
+  // ---- dY slots of this lane: instruction j of this wave covers tile rows (wave*NDO + j)*(1024/LO) + lane/SO
+  int d_row[NDO];
+  uint32_t d_off[NDO];        // byte offset inside the stage: row*dld*2 + channel bytes; FAR when co is past cout
+#pragma unroll
+  for (int j = 0; j < NDO; ++j) {
+    const int row = (wave * NDO + j) * (1024 / LO) + lane / SO;
+    const int co = cot * TCO + ((lane % SO) ^ wg_swz(row)) * 8;
+    d_row[j] = row;
+    d_off[j] = co < k.cout ? (uint32_t)((row * k.dld + k.doff + co) * 2) : FAR;
+  }
+  // ---- X slots: the column block of a slot is one (tap, channel segment), fixed for the kernel
+  int x_row[NDI], x_cb[NDI];
+  sfk_tap x_tap[NDI];
+  bool x_ok[NDI];
+#pragma unroll
+  for (int j = 0; j < NDI; ++j) {
+    const int row = (wave * NDI + j) * (1024 / LI) + lane / SI;
+    const int colseg = cit * SI + ((lane % SI) ^ wg_swz(row));      // 8-channel segment index on the (tap, cin) axis
+    uint32_t tap, cseg;
+    k.dspt.divmod((uint32_t)colseg, tap, cseg);
+    x_row[j] = row;
+    x_ok[j] = tap < (uint32_t)k.ntaps;
+    x_tap[j] = k.taps[x_ok[j] ? tap : 0];
+    x_cb[j] = ((int)cseg * 8 + k.xoff) * 2;
+  }
+  // pointwise stride-1 conv: X advances like dY
+  const bool linear = k.ntaps == 1 && k.taps[0].dt == 0 && k.taps[0].dh == 0 && k.taps[0].dw == 0 && k.gst == 1 &&
+                      k.gsh == 1 && k.gsw == 1 && k.xt == (int)k.drt.d && k.xh == (int)k.drh.d && k.xw == (int)k.drw.d;
+  uint32_t x_lin[NDI];
+#pragma unroll
+  for (int j = 0; j < NDI; ++j) x_lin[j] = x_ok[j] ? (uint32_t)(x_row[j] * k.xld * 2 + x_cb[j]) : FAR;
+
+  auto dma = [&](int stage, int buf) {
+    char* ds = smem + buf * BUF;
+    char* xs = ds + TILEO;
+    const int m0 = stage * R;
+    const bool full = m0 + R <= k.M;                  // wave-uniform; the ragged last stage masks rows per lane
+    const bool live = stage < stage1;                 // look-ahead past the block's range gathers nothing
+#pragma unroll
+    for (int j = 0; j < NDO; ++j) {
+      uint32_t vo = d_off[j];
+      int so = m0 * k.dld * 2;
+      if (!live || (!full && m0 + d_row[j] >= k.M)) vo = FAR;
+      if (!live) so = 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(ds + (wave * NDO + j) * 1024), 16, (int)vo, so, 0, 0);
+    }
+    if (linear) {
+#pragma unroll
+      for (int j = 0; j < NDI; ++j) {
+        uint32_t vo = x_lin[j];
+        int so = m0 * k.xld * 2;
+        if (!live || (!full && m0 + x_row[j] >= k.M)) vo = FAR;
+        if (!live) so = 0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16, (int)vo, so, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDI; ++j) {
+        const int m = m0 + x_row[j];
+        uint32_t q1, rw_, q2, rh_, n_, rt_;
+        k.drw.divmod((uint32_t)m, q1, rw_);
+        k.drh.divmod(q1, q2, rh_);
+        k.drt.divmod(q2, n_, rt_);
+        const int ti = (int)rt_ * k.gst + x_tap[j].dt, hi = (int)rh_ * k.gsh + x_tap[j].dh, wi = (int)rw_ * k.gsw + x_tap[j].dw;
+        const bool ok = live && x_ok[j] && m < k.M && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
+                        (unsigned)wi < (unsigned)k.xw;
+        const uint32_t pix = (((uint32_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16,
+                                                 (int)(ok ? pix * (uint32_t)(k.xld * 2) + (uint32_t)x_cb[j] : FAR), 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transpose-read addresses (loop-invariant): lane (g, q, p) reads row 8g+q (+4), channels c0+4p..+3
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int frow = 8 * g + q, fs = wg_swz(frow);
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = frow * LO + (((wco * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
+    b_off[i] = TILEO + frow * LI + (((wci * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
+  }
+  auto rd = [&](int off, int rowb) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off + 4 * rowb));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  };
+  auto compute = [&](int slot_base) {
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = rd(slot_base + a_off[i], LO);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = rd(slot_base + b_off[j], LI);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  auto ring_wait = [&]() {
+    static_assert(NDO + NDI >= 2 && NDO + NDI <= 4, "DMA count");
+    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  dma(stage0, 0);
+  dma(stage0 + 1, 1);
+  ring_wait();
+  for (int st = stage0;;) {
+    dma(st + 2, 2); compute(0 * BUF); ring_wait();
+    if (++st >= stage1) break;
+    dma(st + 2, 0); compute(1 * BUF); ring_wait();
+    if (++st >= stage1) break;
+    dma(st + 2, 1); compute(2 * BUF); ring_wait();
+    if (++st >= stage1) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // D[row = co][col]: lane holds co = 4*(lane>>4) + r and column lane & 15
+  const int l15 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = cit * TCI + wci * 64 + 16 * j + l15;
+    uint32_t tap, ci;
+    k.dcin.divmod((uint32_t)col, tap, ci);
+    if (tap >= (uint32_t)k.ntaps) continue;
+    const int widx = k.taps[tap].widx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * TCO + wco * 64 + 16 * i + 4 * g + r;
+        if (co < k.cout) atomicAdd(k.dw + ((int64_t)co * k.wtaps + widx) * k.cin + ci, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int TCO, int NW>
+int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
+  const int cols = d->ntaps * d->cin;
+  const int cotiles = (d->cout + TCO - 1) / TCO;
+  k.citiles = (cols + 127) / 128;
+  k.nchunks = (k.M + MK - 1) / MK;
+  const int base = cotiles * k.citiles;
+  // pixel splits: one resident generation of workgroups (2 x 256 CUs for the 8-wave tile, 3 x 256 for the 4-wave one).
+  // Every split adds a full copy of the tile to the fp32 atomic traffic (~1.3 TB/s chip-wide), so do not over-split.
+  int splits = ((NW == 8 ? 512 : 768) + base - 1) / base;
+  const int max_splits = (k.nchunks + 7) / 8;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  k.chunks_per_split = (k.nchunks + splits - 1) / splits;
+  splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)base, 1, (unsigned)splits), dim3(64 * NW), 0, s, k);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
 int validate(const sfk_wgrad_desc* d) {
   if (!d || !d->dw) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->dy)) return SFK_ERR_INVALID;
@@ -244,7 +448,7 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
   k.nchunks = (k.M + R - 1) / R;
   // pixel splits: enough workgroups to cover the 256 CUs several times, at least 4 stages each
   const int base = cotiles * k.citiles;
-  int splits = (2048 + base - 1) / base;
+  int splits = (1024 + base - 1) / base;
   const int max_splits = (k.nchunks + 3) / 4;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -272,6 +476,11 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s) {
   k.dbytes = (uint32_t)sfk_fmap_bytes(&d->dy);
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
   const int cols = d->ntaps * d->cin;
+  if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
+    // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
+    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s);
+    return launch_dma<128, 4>(k, d, s);
+  }
   if (cols <= 32) {
     if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s);
     if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s);
