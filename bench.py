@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--classes", type=int, default=400)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (serialises the two pathway streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -127,7 +127,7 @@ def main():
     labels = torch.randint(0, args.classes, (B,), generator=gen).to(dev)
     idx = pack_pathway_index(32, 4, dev)                   # slow pathway = frames [0,4,8,13,17,22,26,31]
     reducer = sdist.GradReducer(eng.G, bucket_mb=32.0) if world > 1 else None
-    step = TrainStep(eng, lr=2e-4, use_graph=not args.no_graph, reducer=reducer)
+    step = TrainStep(eng, lr=2e-4, use_graph=args.graph, reducer=reducer)
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,7 +156,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "config/slowfast-Torso.yaml path at the metric geometry: SlowFast-R50 8x8, "
                                "3x32x224^2 clips, fwd+CE+bwd+Adam", "clips_per_gpu": B, "global_batch": B * world,
-                   "classes": args.classes, "parallelism": f"dp{world}", "hipgraph": bool(step.use_graph),
+                   "classes": args.classes, "parallelism": f"dp{world}", "hipgraph": bool(step.use_graph), "pathway_streams": 2 if eng.two_streams else 1,
                    "params": eng.num_parameters()},
         "loss_after": round(final_loss, 4),
     }

@@ -29,9 +29,13 @@ from .slowfast import init_my_slowfast
 
 
 class TrainStep:
-    """One optimisation step on one rank: forward -> mean cross-entropy -> backward -> (all-reduce) -> Adam."""
+    """One optimisation step on one rank: forward -> mean cross-entropy -> backward -> (all-reduce) -> Adam.
 
-    def __init__(self, engine: Engine, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
+    Default execution is eager on two HIP streams (slow / fast pathway, engine.OpList): measured 46.5 ms/step vs
+    51.7 ms for the same schedule replayed as ONE hipGraph, whose replay serialises the two branches on this ROCm;
+    ``use_graph=True`` keeps the single-graph replay (lowest host load)."""
+
+    def __init__(self, engine: Engine, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = False,
                  reducer: Optional[sdist.GradReducer] = None, overlap_segments: int = 6):
         self.eng, self.lr, self.betas, self.eps = engine, lr, betas, eps
         self.reducer = reducer
@@ -180,7 +184,7 @@ class SyntheticChalearn(torch.utils.data.Dataset):
 
 
 class Trainer:
-    def __init__(self, cfg, train_loader=None, test_loader=None, device="cuda", backend=None, use_graph: bool = True):
+    def __init__(self, cfg, train_loader=None, test_loader=None, device="cuda", backend=None, use_graph: bool = False):
         self.debug = cfg.DEBUG
         self.num_workers = 0 if self.debug else min(cfg.NUM_CPU, 10)
         self.cfg = cfg
