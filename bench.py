@@ -31,6 +31,23 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 achievable (same guide)
 MFMA_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
 
 
+def pmc_traffic(kind: str):
+    """HBM bytes per launch of kernel class `kind` from the newest committed PMC summary (tools/gpu_traffic.sh:
+    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this very command, gfx950 correction applied)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)["classes"].get(kind)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    if not c or not c.get("launches"):
+        return None, None
+    return int(c["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def instrumented_step(step, pl, frames, labels, idx):
     """One eager step with a HIP event pair around every kernel of the schedule (same stream the kernels launch on).
     Returns {kind: {'ms', 'flops', 'bytes', 'launches'}}."""
@@ -66,8 +83,10 @@ def instrumented_step(step, pl, frames, labels, idx):
         kind = meta["kind"]
         if kind in ("conv_fwd", "conv_dgrad"):
             kind = "conv_igemm"
-        d = out.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        d = out.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "roof_ms": 0.0})
         d["ms"] += a.elapsed_time(b)
+        d["roof_ms"] += 1e3 * max(meta.get("flops", 0.0) / (PEAK_MFMA_BF16_TFLOPS * 1e12),
+                                  meta.get("bytes", 0.0) / (PEAK_HBM_GBS * 1e9))
         d["flops"] += meta.get("flops", 0.0)
         d["bytes"] += meta.get("bytes", 0.0)
         d["launches"] += 1
@@ -180,12 +199,19 @@ def main():
             ach = d["flops"] / sec / 1e12
             line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_BF16_TFLOPS,
                                 "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_BF16_TFLOPS, 4), "traffic": None,
-                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"]}
+                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"],
+                                "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
+                                # the class mixes MFMA- and HBM-bound layers: sum over launches of max(flops/peak,
+                                # bytes/peak) / measured time, both chip peaks as above
+                                "layerwise_frac": round(d["roof_ms"] / d["ms"], 4)}
         else:
             ach = d["bytes"] / sec / 1e9
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                                 "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                                 "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"]}
+        line["roofline"]["traffic"], src = pmc_traffic(dom)
+        if src:
+            line["roofline"]["traffic_source"] = src
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 1
+#define SFK_ABI_VERSION 2
 #define SFK_MAX_TAPS 16
+#define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
 typedef void* sfk_stream_t; /* hipStream_t */
 
@@ -172,11 +173,14 @@ int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, float* dw, sf
 
 /* Training forward, step 1: reduce `nparts` partial (sum, sumsq) rows -> batch mean / biased var; writes
  * mean, invstd, the fused scale = gamma*invstd and shift = beta - mean*scale, and updates
- * running_mean/var (unbiased var, momentum) and num_batches_tracked exactly as nn.BatchNorm3d does. */
+ * running_mean/var (unbiased var, momentum) and num_batches_tracked exactly as nn.BatchNorm3d does.
+ * workspace: NULL, or [SFK_BN_FOLD_ROWS][c][2] floats of scratch: with it, more than 2*SFK_BN_FOLD_ROWS rows are
+ * first folded down by a grid of workgroups (a conv over a large map leaves thousands of rows). Either way the sums
+ * are accumulated in double in a fixed order (deterministic). */
 int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
-                    sfk_stream_t stream);
+                    float* workspace, sfk_stream_t stream);
 
 /* Eval forward: scale/shift from the running statistics. */
 int sfk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
@@ -205,7 +209,8 @@ int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mas
                       const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
                       sfk_stream_t stream);
 int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
-                        const float* invstd, float* dgamma, float* dbeta, float* coef, sfk_stream_t stream);
+                        const float* invstd, float* dgamma, float* dbeta, float* coef, float* workspace,
+                        sfk_stream_t stream); /* workspace: as sfk_bn_finalize */
 int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                      const float* invstd, const float* scale, const float* shift, int32_t relu,
                      const float* coef, const sfk_fmap* dy, sfk_stream_t stream);

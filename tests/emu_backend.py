@@ -167,7 +167,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ batch norm
     def bn_finalize(self, partials, nparts, c, count, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale,
-                    shift):
+                    shift, workspace=None):
         def run(stream):
             pt = partials[: nparts * c * 2].view(nparts, c, 2).double().sum(0)
             mu = pt[:, 0] / count
@@ -237,7 +237,7 @@ class EmuBackend:
                 dz_out.view5().copy_(dz.to(dz_out.dtype))
         return run, 1
 
-    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef):
+    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef, workspace=None):
         def run(stream):
             pt = partials[: nparts * c * 2].view(nparts, c, 2).double().sum(0)
             if dgamma is not None:

@@ -221,6 +221,41 @@ def test_stem_conv_direct(hip, dtype, src_dtype, case):
     assert torch.equal(dwg.cpu().view(cout, kp)[pad], base.view(cout, kp)[pad])
 
 
+@pytest.mark.parametrize("c,nparts", [(8, 50176), (256, 3136), (80, 129), (2048, 300), (64, 128)],
+                         ids=lambda v: str(v))
+def test_batchnorm_partial_fold_two_level(hip, c, nparts):
+    """sfk_bn_finalize / sfk_bn_bwd_finalize with the fold workspace (thousands of partial rows, as a conv over the
+    benchmark's stem / res2 maps leaves them) == without it == a double-precision fold on the host."""
+    from video_classification_amd._lib import BN_FOLD_ROWS
+    gen = torch.Generator().manual_seed(c + nparts)
+    parts = (torch.rand(nparts, c, 2, generator=gen) + 0.5)
+    parts[:, :, 1] += 3.0                      # sumsq rows > sum^2 / count
+    count = nparts * 4
+    gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen)
+    f = lambda *sh, **k: torch.zeros(*sh, device=DEV, **k)
+    pg = parts.reshape(-1).to(DEV)
+    outs = []
+    for ws in (None, f(BN_FOLD_ROWS * c * 2)):
+        rm, rv, nbt = f(c), torch.ones(c, device=DEV), f(1, dtype=torch.int64)
+        mean, invstd, scale, shift = f(c), f(c), f(c), f(c)
+        hip.bn_finalize(pg, nparts, c, count, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv, nbt, mean, invstd, scale,
+                        shift, ws)(stream())
+        dgamma, dbeta, coef = f(c), f(c), f(c * 3)
+        hip.bn_bwd_finalize(pg, nparts, c, count, gamma.to(DEV), invstd, dgamma, dbeta, coef, ws)(stream())
+        torch.cuda.synchronize()
+        outs.append([t.cpu() for t in (mean, invstd, scale, shift, rm, rv, dgamma, dbeta, coef)])
+        assert int(nbt) == 1
+    tot = parts.double().sum(0)
+    mu = tot[:, 0] / count
+    var = tot[:, 1] / count - mu * mu
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 1e-6
+    for o in outs:
+        assert rel_err(o[0], mu.float()) < 1e-6
+        assert rel_err(o[1], (1.0 / torch.sqrt(var + 1e-5)).float()) < 1e-5
+        assert rel_err(o[6], tot[:, 1].float()) < 1e-6 and rel_err(o[7], tot[:, 0].float()) < 1e-6
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("c", [8, 64, 80, 2048], ids=lambda c: f"c{c}")
 def test_batchnorm_forward_backward(hip, dtype, c):

@@ -18,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsfk.so")
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
+ABI_VERSION = 2        # include/sfk.h SFK_ABI_VERSION
+BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
 
@@ -176,13 +178,13 @@ SIGNATURES = {
     "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
     "sfk_stem_conv_fwd": [C.POINTER(_StemSrc), _PV, _P_FMAP, _PF, _PV],
     "sfk_stem_conv_wgrad": [C.POINTER(_StemSrc), _P_FMAP, _PF, _PV],
-    "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PV],
+    "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
     "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
     "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV],
     "sfk_bn_bwd_reduce": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _P_FMAP, _PF, _I32,
                           C.POINTER(C.c_int32), _PV],
-    "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PV],
+    "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_bwd_apply": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _PF, _P_FMAP, _PV],
     "sfk_maxpool_fwd": [_P_FMAP, _P_FMAP, _PV, _I32, _I32, _I32, _PV],
     "sfk_maxpool_bwd": [_P_FMAP, _PV, _P_FMAP, _I32, _I32, _I32, _PV],
@@ -217,7 +219,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.sfk_abi_version() != 1:
+    if lib.sfk_abi_version() != ABI_VERSION:
         raise SfkError("libsfk ABI version mismatch")
     _lib = lib
     return lib
@@ -361,11 +363,12 @@ class HipBackend:
         return run
 
     def bn_finalize(self, partials, nparts, c, count, gamma, beta, eps, momentum, running_mean, running_var, nbt,
-                    mean, invstd, scale, shift):
-        ts = (partials, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift)
+                    mean, invstd, scale, shift, workspace=None):
+        """workspace: optional BN_FOLD_ROWS * c * 2 floats (parallel first-level fold of many partial rows)"""
+        ts = (partials, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, workspace)
         return self._plain("sfk_bn_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
                            _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd), _ptr(scale),
-                           _ptr(shift), keep=ts)
+                           _ptr(shift), _ptr(workspace), keep=ts)
 
     def bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift):
         return self._plain("sfk_bn_eval_coeffs", _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), eps, c, _ptr(scale),
@@ -413,9 +416,10 @@ class HipBackend:
                           keep=(fa, fy, fm, fz, np_, da, y, mask_src, dz_out, mean, invstd, scale, shift, partials))
         return run, self._dry_parts(y, max_parts)
 
-    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef):
+    def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef, workspace=None):
         return self._plain("sfk_bn_bwd_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(invstd),
-                           _ptr(dgamma), _ptr(dbeta), _ptr(coef), keep=(partials, gamma, invstd, dgamma, dbeta, coef))
+                           _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(workspace),
+                           keep=(partials, gamma, invstd, dgamma, dbeta, coef, workspace))
 
     def bn_bwd_apply(self, da: FMap, y: FMap, mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool, coef,
                      dy: FMap):

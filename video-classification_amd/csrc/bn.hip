@@ -100,6 +100,50 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(FM y, int64_t pixels, int
   block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
 }
 
+// Folding the partial rows.  A conv over the benchmark's res2 maps leaves 3,136 rows x 256 channels (the fast stem
+// 50,176 x 8), so the fold is split: bn_fold_kernel reduces `nparts` rows to <= SFK_BN_FOLD_ROWS rows with coalesced
+// reads (64 adjacent channels per wave-row = 512 B), then one wave per channel folds those in the finalize kernel.
+// Both levels accumulate in double and in a fixed order: deterministic, no atomics.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ partials, int nparts, int c, int per,
+                                                      float* __restrict__ out) {
+  __shared__ double red[2][4][64];
+  const int tx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
+  const int r0 = blockIdx.x * per;
+  int r1 = r0 + per;
+  if (r1 > nparts) r1 = nparts;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c) {
+    for (int p = r0 + rl; p < r1; p += 4) {
+      const float2 v = *reinterpret_cast<const float2*>(partials + ((int64_t)p * c + ch) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  }
+  red[0][rl][tx] = s1;
+  red[1][rl][tx] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    const double a = ((red[0][0][tx] + red[0][1][tx]) + red[0][2][tx]) + red[0][3][tx];
+    const double b = ((red[1][0][tx] + red[1][1][tx]) + red[1][2][tx]) + red[1][3][tx];
+    *reinterpret_cast<float2*>(out + ((int64_t)blockIdx.x * c + ch) * 2) = make_float2((float)a, (float)b);
+  }
+}
+
+// returns the rows left to fold (in `*rows_out`) and where they are; launches the first level when it pays
+inline const float* fold_partials(const float* partials, int nparts, int c, float* workspace, int* rows_out,
+                                  hipStream_t s) {
+  if (!workspace || nparts <= 2 * SFK_BN_FOLD_ROWS) {
+    *rows_out = nparts;
+    return partials;
+  }
+  const int per = (nparts + SFK_BN_FOLD_ROWS - 1) / SFK_BN_FOLD_ROWS;
+  const int rows = (nparts + per - 1) / per;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(rows, (c + 63) / 64), dim3(256), 0, s, partials, nparts, c, per, workspace);
+  *rows_out = rows;
+  return workspace;
+}
+
 // one wave per channel: lanes stride over the partial rows, butterfly in double
 __device__ __forceinline__ void wave_sum_partials(const float* partials, int nparts, int c, int ch, double& s1,
                                                   double& s2) {
@@ -320,11 +364,13 @@ extern "C" int sfk_bn_stats(const sfk_fmap* y, float* partials, int32_t max_part
 extern "C" int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
-                               float* scale, float* shift, sfk_stream_t stream) {
+                               float* scale, float* shift, float* workspace, sfk_stream_t stream) {
   if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift)
     return SFK_ERR_INVALID;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SFK_ERR_INVALID;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, s, partials,
                      nparts, c, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
                      num_batches_tracked, mean, invstd, scale, shift);
   SFK_CHECK_LAUNCH();
@@ -439,9 +485,11 @@ extern "C" int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sf
 
 extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef,
-                                   sfk_stream_t stream) {
+                                   float* workspace, sfk_stream_t stream) {
   if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !invstd || !coef) return SFK_ERR_INVALID;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, s,
                      partials, nparts, c, (double)count, gamma, invstd, dgamma, dbeta, coef);
   SFK_CHECK_LAUNCH();
   return SFK_OK;

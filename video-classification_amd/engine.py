@@ -20,7 +20,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import arch
-from ._lib import ConvPass, FMap, StemSrc, WgradPass, stem_kp
+from ._lib import BN_FOLD_ROWS, ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
@@ -319,6 +319,10 @@ class Engine:
         ld = c if ld is None else ld
         return FMap(self._buf(tag, n * t * h * w * ld), n, t, h, w, c, ld, 0)
 
+    def _fold_ws(self, tag: str, c: int) -> torch.Tensor:
+        """scratch of the two-level BatchNorm partial fold (sfk_bn_finalize); one per unit: the pathways overlap"""
+        return self._buf(f"foldws.{tag}", BN_FOLD_ROWS * c * 2, torch.float32)
+
     def _pslice(self, off: int, n: int) -> torch.Tensor:
         return self.P.data[off:off + n]
 
@@ -356,7 +360,8 @@ class Engine:
             mean = self._buf(f"mean.{tag}", L.c, torch.float32)
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
             pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
-                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift))
+                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
+                                              self._fold_ws(tag, L.c)))
             rec = _UnitRec(L, x, y, mean, invstd, scale, shift)
         else:
             self._conv(pl, L, x, y, None)
@@ -381,7 +386,8 @@ class Engine:
         pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
                       bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0)))
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
-                                              self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef))
+                                              self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
+                                              self._fold_ws(tag, L.c)))
         pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
         if dz_inplace:   # the mask is already applied to da
             pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False,
@@ -467,7 +473,8 @@ class Engine:
             mean = self._buf(f"mean.{tag}", L.c, torch.float32)
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
             pl.fwd.append(self.be.bn_finalize(st["stats"], mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
-                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift))
+                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
+                                              self._fold_ws(tag, L.c)))
             rec = _UnitRec(L, None, y, mean, invstd, scale, shift)
         else:
             self._stem_ops(pl, p, x5, t_index)
