@@ -57,10 +57,15 @@ def instrumented_step(step, pl, frames, labels, idx):
     ev = []
 
     def timed(oplist):
-        for op, meta in zip(oplist, oplist.meta):
-            if meta is None:
+        from video_classification_amd.engine import Wait
+        per_layer = bool(os.environ.get("SFK_PER_LAYER"))
+        for op, meta, lane in zip(oplist, oplist.meta, oplist.lane):
+            if meta is None and (not per_layer or isinstance(op, Wait)):
                 op(st)
                 continue
+            if meta is None:
+                meta = {"kind": "misc"}      # finalize / pool / head kernels: timed only for the per-layer dump
+            meta = dict(meta, lane=lane)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             op(st)
@@ -81,6 +86,8 @@ def instrumented_step(step, pl, frames, labels, idx):
             json.dump(rows, f)
     for meta, a, b in ev:
         kind = meta["kind"]
+        if kind == "misc":
+            continue
         if kind in ("conv_fwd", "conv_dgrad"):
             kind = "conv_igemm"
         d = out.setdefault(kind, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "roof_ms": 0.0})

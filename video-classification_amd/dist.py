@@ -75,16 +75,22 @@ class GradReducer:
     def begin(self):
         self.reduced = []
 
-    def reduce(self, ranges: Sequence[Range]):
+    def reduce(self, ranges: Sequence[Range], producers: Optional[Sequence["torch.cuda.Stream"]] = None):
+        """producers: the streams that wrote these gradient ranges (default: the current stream); the exchange
+        starts once everything issued on them so far has finished."""
         if self.world == 1:
             return
         ranges = split_ranges(merge_ranges(ranges), self.bucket_numel)
         self.reduced += ranges
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.g.device))
+            evs = []
+            for s in (producers or [torch.cuda.current_stream(self.g.device)]):
+                ev = torch.cuda.Event()
+                ev.record(s)
+                evs.append(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 for off, n in ranges:
                     dist.all_reduce(self.g[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
         else:

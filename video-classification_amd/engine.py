@@ -732,17 +732,29 @@ class Engine:
         for op in ops:
             op(stream)
 
-    def _run_lanes(self, ops: "OpList"):
-        """Run a schedule on two streams: pathway 0 on the current stream, pathway 1 on a side stream, ordered by
-        the Wait markers (events).  Capturable: the side stream forks from / joins into the capturing stream."""
-        if self.device.type != "cuda" or not self.two_streams:
-            return self._run(ops, self._stream())
+    def lane_streams(self):
+        """torch streams the two pathway lanes run on (one entry when the schedule is single-stream / on the CPU)"""
+        if self.device.type != "cuda":
+            return []
         main = torch.cuda.current_stream(self.device)
+        if not self.two_streams:
+            return [main]
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
-        streams = (main, self._side)
+        return [main, self._side]
+
+    def _run_lanes(self, ops: "OpList", begin: int = 0, end: Optional[int] = None):
+        """Run ops[begin:end] of a schedule on two streams: pathway 0 on the current stream, pathway 1 on a side
+        stream, ordered by the Wait markers (events).  Capturable: the side stream forks from / joins into the
+        capturing stream."""
+        end = len(ops) if end is None else end
+        if self.device.type != "cuda" or not self.two_streams:
+            return self._run(ops[begin:end], self._stream())
+        streams = self.lane_streams()
+        main = streams[0]
         handles = (main.cuda_stream, self._side.cuda_stream)
-        for op, lane in zip(ops, ops.lane):
+        for i in range(begin, end):
+            op, lane = ops[i], ops.lane[i]
             if isinstance(op, Wait):
                 ev = torch.cuda.Event()
                 ev.record(streams[op.on])

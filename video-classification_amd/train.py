@@ -77,8 +77,8 @@ class TrainStep:
         else:
             self.reducer.begin()
             for a, b, ranges in pl.grad_segments(self.overlap_segments):
-                eng._run(pl.bwd[a:b], st)
-                self.reducer.reduce(ranges)
+                eng._run_lanes(pl.bwd, a, b)          # both pathway streams, as the single-rank step
+                self.reducer.reduce(ranges, eng.lane_streams())
             self.reducer.finish()
         ops["adam"](st)
 
