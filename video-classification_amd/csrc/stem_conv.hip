@@ -378,6 +378,337 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemK k) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, v2
+// Canonical fast stem (kt = 5 or 3, cin = 3, cout <= 8), bf16, 16-byte addressable rows.  Two changes of structure
+// against stem_fwd_kernel:
+//   * temporal PAIRS fill the MFMA: M = 16 rows = (jt, co) for output frames to0, to0+1; the K axis walks the
+//     NF = kt+1 input frames both outputs see (row (jt, co) carries filter tap f = f' - jt, zero outside 0..kt-1),
+//     so the 8-channel stem uses all 16 rows instead of 8;
+//   * a block keeps a ROLLING ring of NF input frames of its 16x16 output tile in LDS and walks the clip in time: a
+//     pair loads 2 new frames (16-byte loads) instead of re-staging kt frames per output frame element by element.
+// K order inside a frame: (ci, kh padded to 8, k' = kw + 1) = 24 rows of 8 = 6 MFMA chunks per frame, so the ring
+// rotation is a wave-uniform choice of the A chunk block (scalar arithmetic), and the kh rows of a chunk are taken in
+// the order {0,2,1,3} so the two 32-lane halves of a ds_read_b32 hit disjoint banks (row pitch 96 B).
+constexpr int F2_PITCH = 96;                 // patch row pitch, bytes (48 columns from wi = 2*wo0 - 8)
+constexpr int F2_PR = 38;                    // patch rows (37 + the row the padded kh = 7 reads)
+constexpr int F2_PLANE = F2_PR * F2_PITCH;   // 3648 B
+
+template <int CIN, int KT>
+__global__ __launch_bounds__(512, 2) void stem_fwd_v2_kernel(const StemK k, int pairs_per_unit, int nunits) {
+  constexpr int NF = KT + 1, PT = KT / 2;
+  constexpr int SLOT = CIN * F2_PLANE;
+  constexpr int CPF = CIN * 2;                                   // MFMA chunks per frame
+  constexpr int NCH = NF * CPF;                                  // chunks of the A matrix
+  constexpr int FRAME_CHUNKS = CIN * F2_PR * 6;                  // 16-byte chunks of one frame patch
+  constexpr int NXC = (2 * FRAME_CHUNKS + 511) / 512;            // per thread, two frames
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                             // [NF][CIN][38][96 B]
+  char* amat = smem + NF * SLOT;                                 // [NCH][16 rows][64 B], 16-B slots XOR-swizzled
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [8 waves][16 rows][2]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bf16_t* src = static_cast<const bf16_t*>(k.src);
+  bf16_t* yp = static_cast<bf16_t*>(k.y);
+  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
+  const int perm_g = ((g & 1) << 1) | (g >> 1);                  // {0,2,1,3}
+
+  // ---- A matrix: amat[chunk f'*CPF + c6][row (jt,co)][k = 8g + k'] = w[co][f'-jt][ci = c6>>1][kh][k'-1]
+  {
+    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
+    for (int e = tid; e < NCH * 64; e += 512) {
+      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
+      const int fp = ch / CPF, c6 = ch % CPF;
+      const int jt = row >> 3, co = row & 7, f = fp - jt;
+      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+      if (f >= 0 && f < KT && co < k.cout && kh < KH) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + ((f * CIN + ci) * KH + kh) * 8);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
+      }
+      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
+    }
+  }
+
+  // ---- staging slots of this thread within a two-frame load: (which of the two frames, ci, row, 16-B chunk)
+  int x_fr[NXC], x_loc[NXC], x_r[NXC], x_j[NXC];
+#pragma unroll
+  for (int i = 0; i < NXC; ++i) {
+    const int e = tid + 512 * i;
+    x_fr[i] = e < 2 * FRAME_CHUNKS ? e / FRAME_CHUNKS : -1;
+    const int rem = e % FRAME_CHUNKS;
+    const int ci = rem / (F2_PR * 6), rr = rem % (F2_PR * 6);
+    x_r[i] = rr / 6;
+    x_j[i] = rr % 6;
+    x_loc[i] = ci * F2_PLANE + x_r[i] * F2_PITCH + x_j[i] * 16;
+    x_j[i] |= ci << 8;                                           // pack ci
+  }
+  uint4 xr[NXC];
+  int n = 0, ho0 = 0, wo0 = 0;
+  // frames F0, F0+1 (logical, may lie outside the clip = temporal zero padding)
+  auto fetch = [&](int F0) {
+#pragma unroll
+    for (int i = 0; i < NXC; ++i) {
+      xr[i] = make_uint4(0, 0, 0, 0);
+      if (x_fr[i] < 0) continue;
+      const int F = F0 + x_fr[i];
+      if (F < 0 || F >= k.t_log) continue;
+      const int frame = k.t_index ? k.t_index[F] : F;
+      const int hi = 2 * ho0 - 3 + x_r[i], wi = 2 * wo0 - 8 + 8 * (x_j[i] & 255), ci = x_j[i] >> 8;
+      if (frame >= 0 && frame < k.t_in && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in)
+        xr[i] = *reinterpret_cast<const uint4*>(src + (int64_t)n * k.sn + (int64_t)ci * k.sc + (int64_t)frame * k.st +
+                                                (int64_t)hi * k.sh + wi);
+    }
+  };
+  auto stage = [&](int F0) {
+#pragma unroll
+    for (int i = 0; i < NXC; ++i) {
+      if (x_fr[i] < 0) continue;
+      const int sl = (F0 + x_fr[i] + 4 * NF) % NF;
+      *reinterpret_cast<uint4*>(ring + sl * SLOT + x_loc[i]) = xr[i];
+    }
+  };
+
+  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
+  const int a_lane = a_off(l15, g);
+  const int tpairs = (k.t_log + 1) / 2;
+  const int tchunks = (tpairs + pairs_per_unit - 1) / pairs_per_unit;
+
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int tc = unit % tchunks;
+    int tile = unit / tchunks, th, tw;
+    tw = tile % k.tiles_w; tile /= k.tiles_w;
+    th = tile % k.tiles_h;
+    n = tile / k.tiles_h;
+    ho0 = th * TS; wo0 = tw * TS;
+    const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);
+    __syncthreads();                                   // the previous unit's ring reads (and the A build) are done
+    for (int f2 = 0; f2 < NF; f2 += 2) {               // NF is even: fill the window of the first pair
+      fetch(2 * p0 - PT + f2);
+      stage(2 * p0 - PT + f2);
+    }
+    __syncthreads();
+    for (int p = p0; p < p1; ++p) {
+      const int to0 = 2 * p;
+      if (p + 1 < p1) fetch(to0 + PT + 2);             // the two frames the next pair adds fly during this pair's MFMAs
+      f32x4 acc[2];
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int base_f = (to0 - PT + 4 * NF) % NF;     // physical slot of f' = 0
+#pragma unroll
+      for (int sl = 0; sl < NF; ++sl) {
+        int fp = sl - base_f;
+        if (fp < 0) fp += NF;                          // wave-uniform
+        const char* ab = amat + fp * CPF * 1024 + a_lane;
+        const char* bb = ring + sl * SLOT + b_lane;
+#pragma unroll
+        for (int c6 = 0; c6 < CPF; ++c6) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + c6 * 1024);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * F2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
+            uint4 bv = make_uint4(q[0], q[1], q[2], q[3]);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8*>(&bv), acc[j], 0, 0, 0);
+          }
+        }
+      }
+      // ---- epilogue: lane holds rows 4g..4g+3 = (jt = g>>1, co = 4*(g&1) + r) of pixel (2*wave + j, l15)
+      const int jt = g >> 1, co0 = 4 * (g & 1), to = to0 + jt;
+      const int wo = wo0 + l15;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ho = ho0 + 2 * wave + j;
+        if (to < k.t_out && ho < k.ho && wo < k.wo && co0 < k.cout) {
+          store4(yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + co0, acc[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[r] += acc[j][r]; s2[r] += acc[j][r] * acc[j][r]; }
+        }
+      }
+      if (k.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int sft = 1; sft < 16; sft <<= 1) {
+            s1[r] += __shfl_xor(s1[r], sft);
+            s2[r] += __shfl_xor(s2[r], sft);
+          }
+          if (l15 == 0) {
+            red[(wave * 16 + 4 * g + r) * 2 + 0] = s1[r];
+            red[(wave * 16 + 4 * g + r) * 2 + 1] = s2[r];
+          }
+        }
+      }
+      __syncthreads();                                 // ring reads of this pair are done; red is complete
+      if (k.stats && tid < 16) {
+        const int sjt = tid >> 3, sco = tid & 7, sto = to0 + sjt;
+        if (sto < k.t_out && sco < k.cout) {
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < 8; ++w_) { a1 += red[(w_ * 16 + tid) * 2]; a2 += red[(w_ * 16 + tid) * 2 + 1]; }
+          const int64_t trow = (((int64_t)n * k.t_out + sto) * k.tiles_h + th) * k.tiles_w + tw;
+          k.stats[(trow * k.cout + sco) * 2 + 0] = a1;
+          k.stats[(trow * k.cout + sco) * 2 + 1] = a2;
+        }
+      }
+      if (p + 1 < p1) stage(to0 + PT + 2);
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ filter gradient, v2
+// The canonical fast stem (5x7x7, 3 -> 8 channels) is where the generic kernel above loses: one MFMA per B fragment
+// built from 8 two-byte LDS reads, the dY tile re-staged once per (frame, channel) plane, element-wise global loads.
+// v2 is INPUT-FRAME stationary: a work item is (clip n, input frame tf, 16x16 output tile).  Its x patch (cin planes)
+// is staged once with 16-byte loads; the dY tiles of the kt output frames that see this input frame
+// (to = tf + kt/2 - f) are staged side by side as [256 pixels][kt*8 channels], so the GEMM is
+//     dW[(f, co)][(ci, kh, kw)] += sum_pixels dYt[pixel][(f, co)] * patch[ci][2*ho + kh][2*wo + kw]
+// with M = kt*8 <= 48 rows (3 MFMA row fragments per B fragment instead of 1).  A B fragment (16 columns = 2 kh x 8 kw,
+// 8 consecutive output pixels per lane) is 8 aligned dword reads + 4 v_perm (even / odd halves = the stride-2 walk).
+// Blocks are persistent over a contiguous range of items and keep dW in registers; one atomic flush at the end.
+// Requires: bf16 clip with unit W stride, 16-byte aligned rows/planes, W % 8 == 0, cout <= 8, kt <= 5, cin == CIN.
+constexpr int V2_PC = 56;                   // patch row pitch in elements (48 used; 112 B keeps the b128 stores aligned)
+constexpr int V2_PR = 38;                   // patch rows (37 + the row the padded kh = 7 column reads)
+constexpr int V2_CH = 6;                    // 16-byte chunks per patch row (48 columns from wi = 2*wo0 - 8)
+constexpr int V2_DROW = 128;                // dY tile row pitch in bytes: 4 blocks of 32 B, block index XOR-swizzled
+
+__device__ __forceinline__ int v2_swz(int px) { return ((px >> 1) & 1) | (((px >> 3) & 1) << 1); }
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_v2_kernel(const StemK k) {
+  constexpr int PLANE = V2_PR * V2_PC * 2;                       // bytes
+  constexpr int NXC = (CIN * V2_PR * V2_CH + 255) / 256;         // patch chunks per thread
+  constexpr int NDC = 5;                                         // dY chunks per thread (one per f; kt <= 5)
+  __shared__ __attribute__((aligned(16))) char smem[CIN * PLANE + 256 * V2_DROW];
+  char* patch = smem;
+  char* dyt = smem + CIN * PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item0 = blockIdx.x * k.tiles_per_block;
+  const int item1 = min(item0 + k.tiles_per_block, k.ntiles);
+  if (item0 >= item1) return;
+  const bf16_t* src = static_cast<const bf16_t*>(k.src);
+  const bf16_t* dyp = static_cast<const bf16_t*>(k.y);
+
+  // ---- staging slots of this thread (fixed): patch chunk (ci, row, j) and dY chunk (pixel, f)
+  int x_ci[NXC], x_r[NXC], x_j[NXC];
+#pragma unroll
+  for (int i = 0; i < NXC; ++i) {
+    const int e = tid + 256 * i;
+    x_ci[i] = e / (V2_PR * V2_CH);
+    const int rem = e % (V2_PR * V2_CH);
+    x_r[i] = rem / V2_CH;
+    x_j[i] = rem % V2_CH;
+    if (e >= CIN * V2_PR * V2_CH) x_ci[i] = -1;
+  }
+  uint4 xr[NXC], dr[NDC];
+  auto fetch = [&](int item) {
+    int n, tf, ho0, wo0;
+    tile_coords(k, item, n, tf, ho0, wo0);
+    int frame = k.t_index ? k.t_index[tf] : tf;
+    const bool fok = frame >= 0 && frame < k.t_in;
+#pragma unroll
+    for (int i = 0; i < NXC; ++i) {
+      const int hi = 2 * ho0 - 3 + x_r[i], wi = 2 * wo0 - 8 + 8 * x_j[i];
+      xr[i] = make_uint4(0, 0, 0, 0);
+      if (fok && x_ci[i] >= 0 && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in)
+        xr[i] = *reinterpret_cast<const uint4*>(src + (int64_t)n * k.sn + (int64_t)x_ci[i] * k.sc +
+                                                (int64_t)frame * k.st + (int64_t)hi * k.sh + wi);
+    }
+    const int ho = ho0 + (tid >> 4), wo = wo0 + (tid & 15);
+    const bool pok = ho < k.ho && wo < k.wo;
+#pragma unroll
+    for (int f = 0; f < NDC; ++f) {
+      const int to = tf + k.pt - f;
+      dr[f] = make_uint4(0, 0, 0, 0);
+      if (f < k.kt && pok && to >= 0 && to < k.t_out)
+        dr[f] = *reinterpret_cast<const uint4*>(dyp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NXC; ++i)
+      if (x_ci[i] >= 0)
+        *reinterpret_cast<uint4*>(patch + x_ci[i] * PLANE + x_r[i] * (V2_PC * 2) + x_j[i] * 16) = xr[i];
+    const int sw = v2_swz(tid);
+#pragma unroll
+    for (int f = 0; f < NDC; ++f)
+      *reinterpret_cast<uint4*>(dyt + tid * V2_DROW + (((f >> 1) ^ sw) << 5) + (f & 1) * 16) = dr[f];
+    // channel block 5 (f = 5) of M fragment 2 is never a real filter tap, but it feeds the MFMA: keep it zero
+    *reinterpret_cast<uint4*>(dyt + tid * V2_DROW + ((2 ^ sw) << 5) + 16) = make_uint4(0, 0, 0, 0);
+  };
+
+  // ---- compute coordinates: this wave owns column fragment cf = wave (kh = 2*wave + khh, kw = l15 & 7)
+  const int khh = l15 >> 3, kw = l15 & 7;
+  const uint32_t sel = (kw & 1) ? 0x05040100u : 0x07060302u;     // odd kw: window column is even -> low halves
+  const int cbe = (kw & 1) ? 5 + kw : 4 + kw;                    // first (even) element of the dword walk
+  const int b_lane = ((g >> 1) * 2 + 2 * wave + khh) * (V2_PC * 2) + (2 * (g & 1) * 8 + cbe) * 2;
+  const int q = l15 >> 2, p4 = lane & 3;
+  int a_lane[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = 8 * g + q;                                   // low 4 bits of the pixel index decide the swizzle
+    a_lane[i] = row * V2_DROW + ((i ^ v2_swz(row)) << 5) + p4 * 8;
+  }
+  f32x4 acc[CIN][3];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(item0);
+  for (int item = item0; item < item1; ++item) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (item + 1 < item1) fetch(item + 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const char* ap = dyt + s * 32 * V2_DROW + a_lane[i];
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ap));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ap + 4 * V2_DROW));
+        a[i][0] = lo[0]; a[i][1] = lo[1]; a[i][2] = lo[2]; a[i][3] = lo[3];
+        a[i][4] = hi[0]; a[i][5] = hi[1]; a[i][6] = hi[2]; a[i][7] = hi[3];
+      }
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(patch + c * PLANE + s * 4 * (V2_PC * 2) + b_lane);
+        uint32_t d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = bp[e];
+        uint4 bv;
+        bv.x = __builtin_amdgcn_perm(d[1], d[0], sel);
+        bv.y = __builtin_amdgcn_perm(d[3], d[2], sel);
+        bv.z = __builtin_amdgcn_perm(d[5], d[4], sel);
+        bv.w = __builtin_amdgcn_perm(d[7], d[6], sel);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&bv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[c][i], 0, 0, 0);
+      }
+    }
+  }
+  // D[row = (f, co)][col = (khh, kw)]: lane holds rows 16i + 4g + r
+  const int kh = 2 * wave + khh;
+  if (kh < KH && kw < 7) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * i + 4 * g + r, f = row >> 3, co = row & 7;
+          if (f < k.kt && co < k.cout)
+            atomicAdd(k.dw + (int64_t)co * k.kp + ((f * CIN + c) * KH + kh) * 8 + kw, acc[c][i][r]);
+        }
+  }
+}
+
 int fill(const sfk_stem_src* s, int cout, int t_out, int ho, int wo, StemK& k) {
   if (!s || !s->src || s->cin <= 0 || s->kt <= 0 || !(s->kt & 1) || s->t_in <= 0 || s->h_in <= 0 || s->w_in <= 0)
     return SFK_ERR_INVALID;
@@ -415,6 +746,27 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
   if (st != SFK_OK) return st;
   if ((y->ld % 4) || (y->c_off % 4) || (((uintptr_t)y->ptr) & 15) || (((uintptr_t)w) & 15)) return SFK_ERR_UNSUPPORTED;
   k.w = w; k.y = y->ptr; k.yld = y->ld; k.yoff = y->c_off; k.stats = stats; k.dw = nullptr;
+  k.ntiles = y->n * y->t * k.tiles_h * k.tiles_w;
+  // canonical fast stem geometry in bf16 with 16-byte addressable rows: temporal pairs over a rolling frame ring
+  if (y->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && (s->kt == 5 || s->kt == 3) && y->c <= 8 &&
+      s->sw == 1 && (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15)) {
+    hipStream_t hs2 = static_cast<hipStream_t>(stream);
+    const int nf = s->kt + 1;
+    const int lds2 = nf * 3 * F2_PLANE + nf * 6 * 1024 + 8 * 16 * 2 * 4;
+    const int tpairs = (k.t_log + 1) / 2;
+    const int ppu = tpairs < 8 ? tpairs : 8;
+    const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
+    const int grid2 = nunits < 256 ? nunits : 256;
+    if (s->kt == 5) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v2_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      hipLaunchKernelGGL((stem_fwd_v2_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds2, hs2, k, ppu, nunits);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v2_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      hipLaunchKernelGGL((stem_fwd_v2_kernel<3, 3>), dim3((unsigned)grid2), dim3(512), lds2, hs2, k, ppu, nunits);
+    }
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   const int fn = (y->c + 15) / 16;
   const size_t esz = y->dtype == SFK_BF16 ? 2 : 4;
   const size_t lds = esz * ((size_t)16 * fn * (k.kp + 8) + (size_t)k.planes * PR * PC) + 4 * 16 * fn * 2 * sizeof(float);
@@ -454,6 +806,18 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
   if (!sfk_fmap_vec_ok(dy)) return SFK_ERR_UNSUPPORTED;
   k.w = nullptr; k.y = dy->ptr; k.yld = dy->ld; k.yoff = dy->c_off; k.stats = nullptr; k.dw = dw;
   k.ntiles = dy->n * dy->t * k.tiles_h * k.tiles_w;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  // canonical fast stem geometry in bf16 with 16-byte addressable rows: the input-frame-stationary kernel
+  if (dy->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && s->kt <= 5 && dy->c <= 8 && s->sw == 1 &&
+      (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15)) {
+    int blocks = 256 * 3;                       // 3 resident workgroups per CU (LDS 44 KB each)
+    if (blocks > k.ntiles) blocks = k.ntiles;
+    k.tiles_per_block = (k.ntiles + blocks - 1) / blocks;
+    blocks = (k.ntiles + k.tiles_per_block - 1) / k.tiles_per_block;
+    hipLaunchKernelGGL((stem_wgrad_v2_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, hs, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   int splits = (2048 + k.planes - 1) / k.planes;
   if (splits > k.ntiles) splits = k.ntiles;
   if (splits > 65535) splits = 65535;
@@ -462,7 +826,6 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
   const int fn = (dy->c + 15) / 16;
   if (fn == 3) return SFK_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)k.planes, (unsigned)splits), blk(256);
-  hipStream_t hs = static_cast<hipStream_t>(stream);
 #define SFK_STEM_WG(T, S)                                                                   \
   do {                                                                                      \
     if (fn == 1) hipLaunchKernelGGL((stem_wgrad_kernel<T, S, 1>), grid, blk, 0, hs, k);     \
