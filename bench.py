@@ -64,7 +64,7 @@ def instrumented_step(step, pl, frames, labels, idx):
                 op(st)
                 continue
             if meta is None:
-                meta = {"kind": "misc"}      # finalize / pool / head kernels: timed only for the per-layer dump
+                meta = {"kind": "misc", "layer": getattr(op, "sfk_name", "?")}   # finalize / pool / head kernels: per-layer dump only
             meta = dict(meta, lane=lane)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()

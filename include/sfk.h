@@ -263,6 +263,23 @@ int sfk_filter_transpose(const void* src, int32_t src_dtype, void* dst, int32_t 
                          int32_t wtaps, int32_t cin, sfk_stream_t stream);
 int sfk_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count,
              sfk_stream_t stream);
+
+/* The per-step refresh of every conv's compute-precision filters from the fp32 master arena (the weights Adam just
+ * updated, train.py:231) in ONE launch: for each table entry, with i over [cout][wtaps][cin],
+ *     s [off + i]                           = (dtype) master[off + i]                     (skipped when s  == NULL)
+ *     st[off + (ci*wtaps + tap)*cout + co]  = (dtype) master[off + (co*wtaps + tap)*cin + ci]   (entries with
+ *                                             transpose != 0; skipped when st == NULL)
+ * `table` is DEVICE memory; entry e owns blocks [first_block, first_block + ceil(cout*wtaps*cin / 2048)), ascending,
+ * and total_blocks is their sum. */
+typedef struct {
+  int64_t off;
+  int32_t cout, wtaps, cin;
+  int32_t first_block;
+  int32_t transpose;
+  int32_t reserved;
+} sfk_filter_ent;
+int sfk_filter_refresh(const float* master, void* s, void* st, int32_t dtype, const sfk_filter_ent* table,
+                       int32_t n_layers, int32_t total_blocks, sfk_stream_t stream);
 int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream);
 
 int sfk_abi_version(void);

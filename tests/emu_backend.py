@@ -396,6 +396,16 @@ class EmuBackend:
             dst[:n].view(cin, wtaps, cout).copy_(src[:n].view(cout, wtaps, cin).permute(2, 1, 0))
         return run
 
+    def filter_refresh(self, master, s, st, layers):
+        def run(stream):
+            for off, cout, wtaps, cin, tr in layers:
+                n = cout * wtaps * cin
+                if s is not None:
+                    s[off:off + n].copy_(master[off:off + n])
+                if st is not None and tr:
+                    st[off:off + n].view(cin, wtaps, cout).copy_(master[off:off + n].view(cout, wtaps, cin).permute(2, 1, 0))
+        return run
+
     def cast(self, src, dst, count):
         def run(stream):
             dst[:count].copy_(src[:count])

@@ -423,3 +423,32 @@ def test_filter_transpose_and_cast(hip, dtype):
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu().view(cin, taps, cout), src.view(cout, taps, cin).permute(2, 1, 0).to(dtype))
     assert torch.equal(sh.cpu(), src.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_filter_refresh_one_launch(hip, dtype):
+    """sfk_filter_refresh == per-layer cast + transpose: several layers (one without a data-gradient copy, one larger
+    than a 2048-element block, ragged tails) from one arena in one launch; bytes outside the layers stay untouched."""
+    gen = torch.Generator().manual_seed(10)
+    shapes = [(24, 3, 40, True), (8, 1, 864, False), (64, 9, 64, True), (4, 1, 8, True)]
+    layers, off = [], 16
+    for cout, taps, cin, tr in shapes:
+        layers.append((off, cout, taps, cin, tr))
+        off += (cout * taps * cin + 7) // 8 * 8 + 8
+    master = torch.randn(off, generator=gen)
+    s = torch.full((off,), 7.0, dtype=dtype, device=DEV)
+    st = torch.full((off,), 7.0, dtype=dtype, device=DEV)
+    hip.filter_refresh(master.to(DEV), s, st, layers)(stream())
+    torch.cuda.synchronize()
+    ws, wst = torch.full((off,), 7.0, dtype=dtype), torch.full((off,), 7.0, dtype=dtype)
+    for o, cout, taps, cin, tr in layers:
+        n = cout * taps * cin
+        ws[o:o + n] = master[o:o + n].to(dtype)
+        if tr:
+            wst[o:o + n] = master[o:o + n].view(cout, taps, cin).permute(2, 1, 0).reshape(-1).to(dtype)
+    assert torch.equal(s.cpu(), ws) and torch.equal(st.cpu(), wst)
+    # transposes only (the parity precision keeps the master arena as its forward copy)
+    st2 = torch.full((off,), 7.0, dtype=dtype, device=DEV)
+    hip.filter_refresh(master.to(DEV), None, st2, layers)(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(st2.cpu(), wst)

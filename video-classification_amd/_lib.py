@@ -198,6 +198,7 @@ SIGNATURES = {
     "sfk_filter_transpose": [_PV, _I32, _PV, _I32, _I32, _I32, _I32, _PV],
     "sfk_cast": [_PV, _I32, _PV, _I32, _I64, _PV],
     "sfk_fill_zero": [_PV, C.c_size_t, _PV],
+    "sfk_filter_refresh": [_PF, _PV, _PV, _I32, _PV, _I32, _I32, _PV],
     "sfk_abi_version": [],
     "sfk_status_string": [C.c_int],
 }
@@ -360,6 +361,7 @@ class HipBackend:
             st = fn(*_a, stream)
             if st:
                 _check(st, name)
+        run.sfk_name = name          # for the profiler's per-op dump
         return run
 
     def bn_finalize(self, partials, nparts, c, count, gamma, beta, eps, momentum, running_mean, running_var, nbt,
@@ -474,6 +476,20 @@ class HipBackend:
 
     def cast(self, src, dst, count):
         return self._plain("sfk_cast", _ptr(src), _DT[src.dtype], _ptr(dst), _DT[dst.dtype], count, keep=(src, dst))
+
+    def filter_refresh(self, master, s, st, layers):
+        """layers: [(arena offset, cout, wtaps, cin, transpose)], one launch for all of them (sfk_filter_refresh)."""
+        import numpy as np
+        ent = np.zeros(len(layers), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("wtaps", "<i4"), ("cin", "<i4"),
+                                                    ("first_block", "<i4"), ("transpose", "<i4"), ("reserved", "<i4")]))
+        fb = 0
+        for i, (off, cout, wtaps, cin, tr) in enumerate(layers):
+            ent[i] = (off, cout, wtaps, cin, fb, 1 if tr else 0, 0)
+            fb += (cout * wtaps * cin + 2047) // 2048
+        table = torch.from_numpy(ent.view(np.uint8).copy()).to(master.device)
+        ref = st if st is not None else s
+        return self._plain("sfk_filter_refresh", _ptr(master), _ptr(s), _ptr(st), _DT[ref.dtype], _ptr(table),
+                           len(layers), fb, keep=(master, s, st, table))
 
     def fill_zero(self, t: torch.Tensor):
         return self._plain("sfk_fill_zero", t.data_ptr(), t.numel() * t.element_size(), keep=(t,))

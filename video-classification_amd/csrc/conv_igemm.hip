@@ -11,6 +11,7 @@
 //   bf16: v_mfma_f32_16x16x32_bf16, LDS rows of 64 B XOR-swizzled so ds_read_b128 is conflict-free
 //   f32 : v_mfma_f32_16x16x4_f32 x8 per K-step (bit-exact fp32 fma chain) -- the parity precision
 #include "sfk_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,6 +27,7 @@ struct ConvK {
   int gst, gsh, gsw, ost, osh, osw, oot, ooh, oow;
   int cin, cout, wtaps, ntaps, KC, accumulate;
   int mtiles, ntiles;
+  int wide_store;   // bf16 output with 16-byte addressable 8-channel groups
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
@@ -87,6 +89,36 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, bool acc) {
   o[0] = (bf16_t)a0; o[1] = (bf16_t)a1; o[2] = (bf16_t)a2; o[3] = (bf16_t)a3;
   *reinterpret_cast<bf16x4*>(p) = o;
 }
+
+// bf16 epilogue with 16-byte stores (guide T21 for the 16x16 fragment): a lane holds 4 consecutive channels of one
+// pixel per co fragment, so the natural store is 8 B and a wave-instruction scatters 16 x 32-B pieces -- the store
+// tail of the output-heavy layers (conv_c, data gradients of conv_a) was issue-bound on them.  v_permlane16_swap
+// between fragments i and i+1 (lanes g^1 are 16 apart) leaves every lane with 8 CONSECUTIVE channels:
+//   g even: fragment i, channels 8*(g>>1)..+7        g odd: fragment i+1, channels 8*(g>>1)..+7
+// half the store instructions, each writing 64 contiguous bytes per pixel.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, f32x4 a, f32x4 b, int g, bool acc) {
+  float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
+  const int co = co_base + 16 * (g & 1) + 8 * (g >> 1);
+  if (co >= cout) return;
+  bf16_t* p = pix + co;
+  if (acc) {
+    const bf16x8 old = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool) {}   // f32 stores are 16 B already
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
@@ -244,10 +276,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
       k.drt.divmod(q2, n_, rt_);
       const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
       const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
 #pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int co = co_w + 16 * i + 4 * g;
-        if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+        for (int i = 0; i < FN; i += 2)
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int co = co_w + 16 * i + 4 * g;
+          if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+        }
       }
     }
   }
@@ -510,10 +548,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
       k.drt.divmod(q2, n_, rt_);
       const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
       const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
 #pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int co = co_w + 16 * i + 4 * g;
-        if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+        for (int i = 0; i < FN; i += 2)
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int co = co_w + 16 * i + 4 * g;
+          if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+        }
       }
     }
   }
@@ -561,10 +605,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
 }
 
 struct TileSel { int bm, bn; };
-inline TileSel pick_tile(int cout, int dtype, int64_t M) {
+inline TileSel pick_tile(int cout, int dtype, int64_t M, int ktot = 1 << 30) {
   // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
   // once the grid still fills the chip
-  if (cout > 64 && dtype == SFK_BF16 && M >= 256 * 128) return {256, 128};
+  static const int small_k = getenv("SFK_SMALLK") ? atoi(getenv("SFK_SMALLK")) : 0;
+  if (cout > 64 && dtype == SFK_BF16 && M >= 256 * 128 && ktot > small_k) return {256, 128};
   if (cout > 64) return {128, 128};
   if (cout > 32) return {256, 64};
   if (cout > 16) return {256, 32};
@@ -620,10 +665,12 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dspt.set(d->cin / vec);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  static const int wide_ok = getenv("SFK_WIDE") ? atoi(getenv("SFK_WIDE")) : 1;   // A/B knob
+  k.wide_store = wide_ok && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  const TileSel ts = pick_tile(d->cout, d->x.dtype, k.M);
+  const TileSel ts = pick_tile(d->cout, d->x.dtype, k.M, d->ntaps * d->cin);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
   const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
@@ -646,7 +693,7 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int st = validate(d);
   if (st != SFK_OK) return st;
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
-  const int bm = pick_tile(d->cout, d->x.dtype, M).bm;
+  const int bm = pick_tile(d->cout, d->x.dtype, M, d->ntaps * d->cin).bm;
   return (int)((M + bm - 1) / bm);
 }
 

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
     di_off[i] = (idx < R * SEGO && co < k.cout) ? (uint32_t)((row * k.dld + k.doff + co) * (int)sizeof(T)) : SFK_OOB;
   }
   uint4 dr[NLO], xr[NLI];
+  const bool linear = k.ntaps == 1 && k.taps[0].dt == 0 && k.taps[0].dh == 0 && k.taps[0].dw == 0 && k.gst == 1 &&
+                      k.gsh == 1 && k.gsw == 1 && k.xt == (int)k.drt.d && k.xh == (int)k.drh.d && k.xw == (int)k.drw.d;
   // branch-free buffer loads: padding taps, rows past M and ragged channels read zeros through SFK_OOB
   auto gload = [&](int stage) {
     const int m0 = stage * R;
@@ -139,6 +141,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
       const int idx = tid + i * 256;
       const bool ok = di_off[i] != SFK_OOB && m0 < k.M && (uint32_t)(idx / SEGO) < rows_left;
       dr[i] = sfk_buffer_load16(drs, ok ? (uint32_t)m0 * (uint32_t)(k.dld * (int)sizeof(T)) + di_off[i] : SFK_OOB);
+    }
+    if (linear) {   // pointwise stride-1 conv: the gathered pixel IS the row (wave-uniform branch, no index arithmetic)
+#pragma unroll
+      for (int i = 0; i < NLI; ++i) {
+        const int m = m0 + xi_row[i];
+        const bool ok = xi_ok[i] && m < k.M;
+        xr[i] = sfk_buffer_load16(xrs, ok ? (uint32_t)m * (uint32_t)(k.xld * (int)sizeof(T)) + (uint32_t)xi_cb[i] : SFK_OOB);
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < NLI; ++i) {

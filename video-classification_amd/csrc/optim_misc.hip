@@ -75,6 +75,37 @@ __global__ __launch_bounds__(256) void filter_transpose_kernel(const S* __restri
   }
 }
 
+// One launch for ALL convs: s[off + i] = cast(master[off + i]) in the forward layout [co][tap][ci] and, for layers with
+// a data-gradient pass, st[off + (ci*wtaps + tap)*cout + co] = the same value.  A block owns 2048 consecutive elements
+// of one layer; the layer is found by bisection of the table's first_block column.
+template <typename D>
+__global__ __launch_bounds__(256) void filter_refresh_kernel(const float* __restrict__ master, D* __restrict__ s,
+                                                             D* __restrict__ st, const sfk_filter_ent* __restrict__ table,
+                                                             int n) {
+  int lo = 0, hi = n - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const sfk_filter_ent e = table[lo];
+  const int64_t total = (int64_t)e.cout * e.wtaps * e.cin;
+  const int64_t i0 = (int64_t)(b - e.first_block) * 2048;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t i = i0 + threadIdx.x + 256 * j;
+    if (i >= total) break;
+    if (s) s[e.off + i] = (D)master[e.off + i];
+    if (st && e.transpose) {
+      const int co = (int)(i % e.cout);
+      const int64_t r = i / e.cout;
+      const int wi = (int)(r % e.wtaps);
+      const int ci = (int)(r / e.wtaps);
+      st[e.off + i] = (D)master[e.off + ((int64_t)co * e.wtaps + wi) * e.cin + ci];
+    }
+  }
+}
+
 struct Im2colK {
   const void* src;
   int64_t sn, sc, st, sh, sw;
@@ -161,6 +192,18 @@ extern "C" int sfk_filter_transpose(const void* src, int32_t src_dtype, void* ds
     hipLaunchKernelGGL((filter_transpose_kernel<bf16_t, float>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, cout, wtaps, cin);
   else
     hipLaunchKernelGGL((filter_transpose_kernel<bf16_t, bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, cout, wtaps, cin);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_filter_refresh(const float* master, void* s, void* st, int32_t dtype, const sfk_filter_ent* table,
+                                  int32_t n_layers, int32_t total_blocks, sfk_stream_t stream) {
+  if (!master || (!s && !st) || !table || n_layers <= 0 || total_blocks <= 0 || !dtype_ok(dtype)) return SFK_ERR_INVALID;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (dtype == SFK_BF16)
+    hipLaunchKernelGGL((filter_refresh_kernel<bf16_t>), dim3((unsigned)total_blocks), dim3(256), 0, hs, master, (bf16_t*)s, (bf16_t*)st, table, n_layers);
+  else
+    hipLaunchKernelGGL((filter_refresh_kernel<float>), dim3((unsigned)total_blocks), dim3(256), 0, hs, master, (float*)s, (float*)st, table, n_layers);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }

@@ -48,9 +48,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o.set(i, best[i]);
     o.store(static_cast<T*>(y.p) + (int64_t)pix * y.ld + y.off + cg * VEC);
-    uint8_t* ap = argmax + (int64_t)pix * c + cg * VEC;
+    // the VEC argmax bytes of this channel group leave as ONE store (8 B for bf16, 4 B for f32)
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) ap[i] = (uint8_t)arg[i];
+    for (int i = 0; i < VEC; ++i) {
+      if (i < 4) lo |= (uint32_t)arg[i] << (8 * i);
+      else hi |= (uint32_t)arg[i] << (8 * (i - 4));
+    }
+    uint8_t* ap = argmax + (int64_t)pix * c + cg * VEC;
+    if (VEC == 8) *reinterpret_cast<uint2*>(ap) = make_uint2(lo, hi);
+    else *reinterpret_cast<uint32_t*>(ap) = lo;
   }
 }
 
@@ -83,9 +90,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(FM dy, const uint8_t* 
         Vec16<T> g;
         g.load(static_cast<const T*>(dy.p) + opix * dy.ld + dy.off + cg * VEC);
         const uint8_t* ap = argmax + opix * c + cg * VEC;
+        uint32_t lo, hi = 0;
+        if (VEC == 8) {
+          const uint2 a2 = *reinterpret_cast<const uint2*>(ap);
+          lo = a2.x; hi = a2.y;
+        } else {
+          lo = *reinterpret_cast<const uint32_t*>(ap);
+        }
 #pragma unroll
-        for (int i = 0; i < VEC; ++i)
-          if (ap[i] == kh * k + kw) acc[i] += g.get(i);
+        for (int i = 0; i < VEC; ++i) {
+          const uint32_t a = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xFFu;
+          if (a == (uint32_t)(kh * k + kw)) acc[i] += g.get(i);
+        }
       }
     }
     Vec16<T> o;
@@ -134,6 +150,72 @@ __global__ __launch_bounds__(256) void head_pool_fwd_kernel(FM x, int n, int c, 
         total += sum * inv_win * inv_keep;
       }
   feat[(int64_t)ni * feat_ld + f_off + ch] = total / (float)(pt * ph * pw);
+}
+
+// Single-position head (the window covers the whole map: canonical (8,7,7) / (32,7,7) pools of the 8x8 model): the
+// dropout decision depends on (sample, feature) only, so it is drawn once per channel and the map is reduced by 32
+// pixel slices of 16-byte loads per workgroup -- the per-(n, channel) thread of the general kernel walks 392..1568
+// two-byte loads serially.  grid = (c / 256 rounded up, n), block = 1024 = 32 channel groups of 8 x 32 slices.
+template <typename T>
+__global__ __launch_bounds__(1024) void head_pool1_fwd_kernel(FM x, int c, float rate, const uint64_t* seedp, float* feat,
+                                                              int feat_ld, int f_off) {
+  constexpr int VEC = DT<T>::VEC;
+  constexpr int CG = 256 / VEC;                 // channel groups per block (256 channels)
+  constexpr int SL = 1024 / CG;                 // pixel slices
+  __shared__ float red[SL][256 + 8];
+  const int ni = blockIdx.y;
+  const int cgl = threadIdx.x % CG, sl = threadIdx.x / CG;
+  const int ch0 = blockIdx.x * 256 + cgl * VEC;
+  const int pixels = x.t * x.h * x.w;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (ch0 < c) {
+    const T* base = static_cast<const T*>(x.p) + (int64_t)ni * pixels * x.ld + x.off + ch0;
+    for (int px = sl; px < pixels; px += SL) {
+      Vec16<T> v;
+      v.load(base + (int64_t)px * x.ld);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v.get(i);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[sl][cgl * VEC + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch < c) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < SL; ++r) s += red[r][threadIdx.x];
+      float scale = 1.f / (float)pixels;
+      if (rate > 0.f) scale = keep_of(seedp[0], ni, f_off + ch, 0, rate) ? scale / (1.f - rate) : 0.f;
+      feat[(int64_t)ni * feat_ld + f_off + ch] = s * scale;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool1_bwd_kernel(const float* dfeat, int feat_ld, int f_off, FM dx, int c,
+                                                             float rate, const uint64_t* seedp, int px_per_block) {
+  constexpr int VEC = DT<T>::VEC;
+  const int ni = blockIdx.z;
+  const int cgs = c / VEC, cgs_b = cgs < 256 ? cgs : 256, rows_b = 256 / cgs_b;
+  const int cg = blockIdx.y * 256 + threadIdx.x % cgs_b, row = threadIdx.x / cgs_b;
+  if (cg >= cgs || row >= rows_b) return;
+  const int pixels = dx.t * dx.h * dx.w;
+  float scale = 1.f / (float)pixels;
+  Vec16<T> o;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = cg * VEC + i;
+    float g = dfeat[(int64_t)ni * feat_ld + f_off + ch] * scale;
+    if (rate > 0.f) g = keep_of(seedp[0], ni, f_off + ch, 0, rate) ? g / (1.f - rate) : 0.f;
+    o.set(i, g);
+  }
+  T* base = static_cast<T*>(dx.p) + (int64_t)ni * pixels * dx.ld + dx.off + cg * VEC;
+  const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, pixels);
+  for (int px = p0 + row; px < p1; px += rows_b) o.store(base + (int64_t)px * dx.ld);
 }
 
 template <typename T>
@@ -322,6 +404,15 @@ extern "C" int sfk_head_pool_fwd(const sfk_fmap* x, int32_t kt, int32_t kh, int3
     return SFK_ERR_INVALID;
   if (rate < 0.f || rate >= 1.f || (rate > 0.f && !seed) || f_off < 0 || feat_ld < f_off + x->c) return SFK_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kt == x->t && kh == x->h && kw == x->w && sfk_fmap_vec_ok(x)) {   // one position: the window is the whole map
+    const dim3 g1((unsigned)((x->c + 255) / 256), (unsigned)x->n);
+    if (x->dtype == SFK_BF16)
+      hipLaunchKernelGGL(head_pool1_fwd_kernel<bf16_t>, g1, dim3(1024), 0, st, fm_of(x), x->c, rate, seed, feat, feat_ld, f_off);
+    else
+      hipLaunchKernelGGL(head_pool1_fwd_kernel<float>, g1, dim3(1024), 0, st, fm_of(x), x->c, rate, seed, feat, feat_ld, f_off);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   const unsigned g = (unsigned)((x->n * x->c + 255) / 256);
   if (x->dtype == SFK_BF16)
     hipLaunchKernelGGL(head_pool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, fm_of(x), x->n, x->c, kt, kh, kw, rate, seed, feat, feat_ld, f_off);
@@ -337,6 +428,19 @@ extern "C" int sfk_head_pool_bwd(const float* dfeat, int32_t feat_ld, int32_t f_
     return SFK_ERR_INVALID;
   if (rate < 0.f || rate >= 1.f || (rate > 0.f && !seed) || f_off < 0 || feat_ld < f_off + dx->c) return SFK_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kt == dx->t && kh == dx->h && kw == dx->w && sfk_fmap_vec_ok(dx)) {
+    const int vec = sfk_vec_of(dx->dtype), cgs = dx->c / vec;
+    const int pixels = dx->t * dx->h * dx->w;
+    int pxb = (pixels + 7) / 8;                     // 8 pixel blocks per (sample, channel chunk)
+    if (pxb < 1) pxb = 1;
+    const dim3 g1((unsigned)((pixels + pxb - 1) / pxb), (unsigned)((cgs + 255) / 256), (unsigned)dx->n);
+    if (dx->dtype == SFK_BF16)
+      hipLaunchKernelGGL(head_pool1_bwd_kernel<bf16_t>, g1, dim3(256), 0, st, dfeat, feat_ld, f_off, fm_of(dx), dx->c, rate, seed, pxb);
+    else
+      hipLaunchKernelGGL(head_pool1_bwd_kernel<float>, g1, dim3(256), 0, st, dfeat, feat_ld, f_off, fm_of(dx), dx->c, rate, seed, pxb);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   const int64_t total = sfk_fmap_pixels(dx) * dx->c;
   if (dx->dtype == SFK_BF16)
     hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, dfeat, feat_ld, f_off, fm_of(dx), dx->n, dx->c, kt, kh, kw, rate, seed);

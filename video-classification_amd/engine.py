@@ -564,14 +564,12 @@ class Engine:
         pl = Plan()
         n = x_fast.shape[0]
         # ---- refresh the compute-precision filter copies from the fp32 master arena
-        if self.dtype != torch.float32:
-            pl.fwd.append(be.cast(self.P.data, self.S, self.conv_total))
-        if train:
-            for L in self.layers:
-                if L.needs_dgrad:
-                    pl.fwd.append(be.filter_transpose(self.S[L.w_off:L.w_off + L.w_numel],
-                                                      self.St[L.w_off:L.w_off + L.w_numel], L.eg.cout, L.eg.wtaps,
-                                                      L.eg.cin))
+        #      (one launch: cast into the forward layout and, for training, the data-gradient transposes)
+        if self.dtype != torch.float32 or train:
+            pl.fwd.append(be.filter_refresh(self.P.data, self.S if self.dtype != torch.float32 else None,
+                                            self.St if train else None,
+                                            [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad)
+                                             for L in self.layers]))
         # ---- geometry after the stems
         def stem_out(x5, p, t_idx):
             g = W.stems[p].geom
