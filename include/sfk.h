@@ -100,8 +100,8 @@ int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats; <0 on er
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_conv_wgrad -- Conv3d filter gradient (autograd of the same nn.Conv3d modules, train.py:230).
  *   dw[co][widx][ci] += sum_rows dY[n,rt,rh,rw,co] * X[n, rt*gs[0]+dt, rh*gs[1]+dh, rw*gs[2]+dw, ci]
- * rows = the pixels of dy (dy.t/h/w are the row extents).  dw is fp32 and is ACCUMULATED into with float
- * atomics (zero it once per step with sfk_fill_zero).  Same alignment rules as sfk_conv_igemm.
+ * rows = the pixels of dy (dy.t/h/w are the row extents).  dw is fp32 and is ACCUMULATED into (zero it once per
+ * step with sfk_fill_zero): through `workspace` when given, else with float atomics.  Same alignment rules as sfk_conv_igemm.
  */
 typedef struct {
   sfk_fmap x, dy;
@@ -110,9 +110,15 @@ typedef struct {
   sfk_tap taps[SFK_MAX_TAPS];
   float* dw; /* [cout][wtaps][cin] fp32 */
   int32_t wtaps, cin, cout;
+  /* optional scratch of >= sfk_conv_wgrad_workspace_bytes(d) bytes (16-byte aligned): the pixel splits then store their
+   * partial tiles with plain 16-byte stores and a second kernel adds them into dw in split order -- deterministic, and
+   * it avoids re-adding every tile through fp32 atomics (~1.3 TB/s chip-wide).  NULL / too small: atomics. */
+  float* workspace;
+  int64_t workspace_bytes;
 } sfk_wgrad_desc;
 
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
+int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d); /* host-side query; <0 on error */
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_stem_im2col -- gathers the stem's (kh x kw x cin) spatial window of every output pixel into a

@@ -92,6 +92,9 @@ class EmuBackend:
                     st[i, :, 1] = (blk * blk).sum(0)
         return run
 
+    def conv_wgrad_workspace_bytes(self, p) -> int:
+        return 0
+
     def conv_wgrad(self, p: WgradPass):
         def run(stream):
             X = p.x.view5().float()

@@ -126,6 +126,27 @@ def test_conv_filter_gradient(hip, dtype, case):
     hip.conv_wgrad(WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), dwg, g.wtaps, cin, cout))(stream())
     torch.cuda.synchronize()
     assert rel_err(dwg.cpu(), dwc) < 5e-5                            # fp32 atomics: order differs, accuracy does not
+    # the workspace path: pixel splits stored as partial tiles and summed in split order -> same values, and two runs
+    # agree BIT FOR BIT (the atomic path does not promise that)
+    wp = WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), None, g.wtaps, cin, cout)
+    wp.dw = base.clone().to(DEV)
+    need = hip.conv_wgrad_workspace_bytes(wp)
+    assert need > 0
+    outs = []
+    for _ in range(2):
+        wp.dw = base.clone().to(DEV)
+        wp.workspace = torch.full((need // 4 + 4,), float("nan"), device=DEV)
+        hip.conv_wgrad(wp)(stream())
+        torch.cuda.synchronize()
+        outs.append(wp.dw.cpu())
+    assert rel_err(outs[0], dwc) < 5e-5
+    assert torch.equal(outs[0], outs[1])
+    # a workspace that is too small falls back to atomics instead of overrunning it
+    wp.dw = base.clone().to(DEV)
+    wp.workspace = torch.zeros(4, device=DEV)
+    hip.conv_wgrad(wp)(stream())
+    torch.cuda.synchronize()
+    assert rel_err(wp.dw.cpu(), dwc) < 5e-5
 
 
 def test_conv_rejects_bad_descriptors(hip):

@@ -13,6 +13,14 @@ LAYERS = {  # cin, cout, k, s, p, (t, h, w)     batch 32
     "c4": (256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 14, 14)),
     "c2": (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)),
     "b2": (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 56, 56)),
+    "b3": (128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 28, 28)),
+    "a2": (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)),
+    # fast pathway (T = 32)
+    "fb2": (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 56, 56)),
+    "fa2": (32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 56, 56)),
+    "fc2": (8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (32, 56, 56)),
+    "fb3": (16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 28, 28)),
+    "fa4": (128, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 14, 14)),
 }
 kind = sys.argv[1] if len(sys.argv) > 1 else "fwd_a4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -38,7 +46,11 @@ elif op == "dgrad":
         runs.append(be.conv_igemm(ConvPass(y, x, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cout, cin)))
 else:
     dw = torch.zeros(cout * g.wtaps * cin, device=dev)
-    runs = [be.conv_wgrad(WgradPass(x, y, g.s, list(wgrad_taps(g)), dw, g.wtaps, cin, cout))]
+    wp = WgradPass(x, y, g.s, list(wgrad_taps(g)), dw, g.wtaps, cin, cout)
+    need = be.conv_wgrad_workspace_bytes(wp)
+    if need > 0 and os.environ.get("SFK_WGWS", "1") != "0":
+        wp.workspace = torch.zeros(need // 4 + 4, device=dev)
+    runs = [be.conv_wgrad(wp)]
 st = torch.cuda.current_stream().cuda_stream
 for r in runs: r(st)
 torch.cuda.synchronize()
@@ -49,4 +61,5 @@ for _ in range(reps):
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / reps
 fl = 2.0 * n * od[0] * od[1] * od[2] * cout * cin * g.wtaps
-print(f"{kind}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
+by = 2.0 * (x.buf.numel() + y.buf.numel())
+print(f"{kind}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s  {by/ms/1e6:.0f} GB/s algorithmic")

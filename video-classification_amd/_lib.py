@@ -98,6 +98,7 @@ class WgradPass:
     wtaps: int
     cin: int
     cout: int
+    workspace: Optional[torch.Tensor] = None   # fp32 scratch for the partial-tile path (sfk_conv_wgrad_workspace_bytes)
 
 
 @dataclass
@@ -147,7 +148,7 @@ class _ConvDesc(C.Structure):
 class _WgradDesc(C.Structure):
     _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32)]
+                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class _Im2colDesc(C.Structure):
@@ -173,6 +174,7 @@ SIGNATURES = {
     "sfk_conv_igemm": [C.POINTER(_ConvDesc), _PV],
     "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
+    "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
     "sfk_stem_kp": [_I32, _I32],
     "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
@@ -202,7 +204,7 @@ SIGNATURES = {
     "sfk_abi_version": [],
     "sfk_status_string": [C.c_int],
 }
-_RESTYPE = {"sfk_status_string": C.c_char_p}
+_RESTYPE = {"sfk_status_string": C.c_char_p, "sfk_conv_wgrad_workspace_bytes": C.c_int64}
 
 _lib = None
 
@@ -290,12 +292,25 @@ class HipBackend:
                 _check(st, "sfk_conv_igemm")
         return run
 
-    def conv_wgrad(self, p: WgradPass):
+    def _wgrad_desc(self, p: WgradPass):
         d = _WgradDesc()
         d.x, d.dy = _c_fmap(p.x), _c_fmap(p.dy)
         d.gs = (C.c_int32 * 3)(*p.gs)
         d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)
         d.dw, d.wtaps, d.cin, d.cout = p.dw.data_ptr(), p.wtaps, p.cin, p.cout
+        return d
+
+    def conv_wgrad_workspace_bytes(self, p: WgradPass) -> int:
+        """bytes of scratch with which sfk_conv_wgrad sums its pixel splits without atomics (deterministically)"""
+        r = self.lib.sfk_conv_wgrad_workspace_bytes(C.byref(self._wgrad_desc(p)))
+        if r < 0:
+            _check(int(r), "sfk_conv_wgrad_workspace_bytes")
+        return int(r)
+
+    def conv_wgrad(self, p: WgradPass):
+        d = self._wgrad_desc(p)
+        if p.workspace is not None:
+            d.workspace, d.workspace_bytes = p.workspace.data_ptr(), p.workspace.numel() * p.workspace.element_size()
         fn = self.lib.sfk_conv_wgrad
 
         def run(stream, _d=C.byref(d), _keep=(d, p)):

@@ -10,6 +10,7 @@
 // kernel packs its K axis), so the taps of narrow layers share one tile and dY is read once per column tile.
 // Grid = (co-tile x column-tile, 1, pixel-split); partial tiles are combined with fp32 atomics into dW.
 #include "sfk_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,10 +28,23 @@ struct WgradK {
   int chunks_per_split, nchunks;  // in stages of KS*32 pixels
   FastDiv dspt, dcin;             // 16-byte segments per tap; channels per tap
   uint32_t xbytes, dbytes;        // extents of the buffer resources
+  float4* ws;                     // partial-tile workspace (NULL: fp32 atomics straight into dw)
+  int ntiles;                     // cotiles * citiles
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
 constexpr int MK = 32;  // pixels per K-step
+
+// XCD-aware block order (as conv_igemm): blocks b, b+8, ... share an L2, so consecutive LOGICAL ids go to one XCD and the
+// tiles of one pixel split (which read the same dY rows and overlapping X rows) are neighbours there.
+__device__ __forceinline__ void wg_block(int ntiles, int& tile, int& split) {
+  const int nblk = gridDim.x, b = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  tile = logical % ntiles;
+  split = logical / ntiles;
+}
+
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -96,8 +110,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave & 1, wci = wave >> 1;
-  const int cot = blockIdx.x / k.citiles, cit = blockIdx.x % k.citiles;
-  const int stage0 = blockIdx.z * k.chunks_per_split;
+  int tile_id, split_id;
+  wg_block(k.ntiles, tile_id, split_id);
+  const int cot = tile_id / k.citiles, cit = tile_id % k.citiles;
+  const int stage0 = split_id * k.chunks_per_split;
   const int stage1 = min(stage0 + k.chunks_per_split, k.nchunks);
   if (stage0 >= stage1) return;
 
@@ -210,6 +226,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
     __syncthreads();
   }
 
+  if (k.ws) {   // partial tile as it lies in the accumulators: 1 KiB per wave-instruction, summed by wgrad_reduce_kernel
+    float4* wp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * 4 + wave) * (FO * FI)) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < FO; ++i)
+#pragma unroll
+      for (int j = 0; j < FI; ++j)
+        wp[(i * FI + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    return;
+  }
   // D[row = co][col]: lane holds co = 4*(lane>>4) + r and column lane & 15 -> 16 lanes add 16 consecutive floats
   const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -257,8 +282,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave % WCO, wci = wave / WCO;
-  const int cot = blockIdx.x / k.citiles, cit = blockIdx.x % k.citiles;
-  const int stage0 = blockIdx.z * k.chunks_per_split;
+  int tile_id, split_id;
+  wg_block(k.ntiles, tile_id, split_id);
+  const int cot = tile_id / k.citiles, cit = tile_id % k.citiles;
+  const int stage0 = split_id * k.chunks_per_split;
   const int stage1 = min(stage0 + k.chunks_per_split, k.nchunks);
   if (stage0 >= stage1) return;
   constexpr uint32_t FAR = 0x80000000u;
@@ -393,6 +420,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if (k.ws) {
+    float4* wp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wp[(i * 4 + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    return;
+  }
   // D[row = co][col]: lane holds co = 4*(lane>>4) + r and column lane & 15
   const int l15 = lane & 15;
 #pragma unroll
@@ -413,8 +449,63 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   }
 }
 
+// Second pass of the workspace path: dw[co][widx][ci] += sum over pixel splits of the partial tiles, in split order
+// (deterministic; fp32 atomics moved ~1.3 TB/s chip-wide and every split re-adds the whole tile).
+// NWV waves per block laid out as WCO x (NWV/WCO), FO x FI accumulator fragments per wave.
+template <int NWV, int WCO, int FO, int FI>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK k, int splits) {
+  constexpr int PER_TILE = NWV * FO * FI * 64;          // float4 per tile
+  constexpr int TCO = WCO * 16 * FO, TCI = (NWV / WCO) * 16 * FI;
+  // 16 consecutive float4 (256 B) per block x 16 split groups; group zg adds splits zg, zg+16, ... in order, then the
+  // 16 group sums are added in order: the summation tree is fixed, whatever the launch does
+  __shared__ float4 red[16][16];
+  const int l16 = threadIdx.x & 15, zg = threadIdx.x >> 4;
+  const int64_t idx = (int64_t)blockIdx.x * 16 + l16;
+  const int64_t total = (int64_t)k.ntiles * PER_TILE;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < total) {
+    const float4* p = k.ws + idx;
+#pragma unroll 4
+    for (int z = zg; z < splits; z += 16) {
+      const float4 v = p[(int64_t)z * total];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+  }
+  red[zg][l16] = sum;
+  __syncthreads();
+  if (zg != 0 || idx >= total) return;
+#pragma unroll
+  for (int z = 1; z < 16; ++z) {
+    const float4 v = red[z][l16];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const int tile = (int)(idx / PER_TILE), e = (int)(idx % PER_TILE);
+  const int lane = e & 63, frag = (e >> 6) % (FO * FI), wave = (e >> 6) / (FO * FI);
+  const int i = frag / FI, j = frag % FI, wco = wave % WCO, wci = wave / WCO;
+  const int cot = tile / k.citiles, cit = tile % k.citiles;
+  const int col = cit * TCI + wci * 16 * FI + 16 * j + (lane & 15);
+  uint32_t tap, ci;
+  k.dcin.divmod((uint32_t)col, tap, ci);
+  if (tap >= (uint32_t)k.ntaps) return;
+  const int widx = k.taps[tap].widx;
+  const int co0 = cot * TCO + wco * 16 * FO + 16 * i + 4 * (lane >> 4);
+  const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (co0 + r < k.cout) k.dw[((int64_t)(co0 + r) * k.wtaps + widx) * k.cin + ci] += v4[r];
+}
+
+template <int NWV, int WCO, int FO, int FI>
+int launch_reduce(const WgradK& k, int splits, hipStream_t s) {
+  constexpr int PER_TILE = NWV * FO * FI * 64;
+  const int64_t total = (int64_t)k.ntiles * PER_TILE;
+  hipLaunchKernelGGL((wgrad_reduce_kernel<NWV, WCO, FO, FI>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, k, splits);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
 template <int TCO, int NW>
-int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
+int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
   k.citiles = (cols + 127) / 128;
@@ -429,8 +520,12 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
   if (splits > 65535) splits = 65535;
   k.chunks_per_split = (k.nchunks + splits - 1) / splits;
   splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)base, 1, (unsigned)splits), dim3(64 * NW), 0, s, k);
+  k.ntiles = base;
+  if (dry) { *dry = (int64_t)splits * base * NW * 16 * 64 * 16; return SFK_OK; }
+  if (k.ws && (int64_t)splits * base * NW * 16 * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
+  if (k.ws) return launch_reduce<NW, TCO / 64, 4, 4>(k, splits, s);
   return SFK_OK;
 }
 
@@ -451,7 +546,7 @@ int validate(const sfk_wgrad_desc* d) {
 }
 
 template <typename T, int TCO, int TCI, int KS>
-int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
+int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
   k.citiles = (cols + TCI - 1) / TCI;
@@ -466,13 +561,18 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s) {
   if (splits > 65535) splits = 65535;
   k.chunks_per_split = (k.nchunks + splits - 1) / splits;
   splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)base, 1, (unsigned)splits), dim3(256), 0, s, k);
+  k.ntiles = base;
+  constexpr int FO = TCO / 32, FI = TCI / 32;
+  if (dry) { *dry = (int64_t)splits * base * 4 * FO * FI * 64 * 16; return SFK_OK; }
+  if (k.ws && (int64_t)splits * base * 4 * FO * FI * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
   SFK_CHECK_LAUNCH();
+  if (k.ws) return launch_reduce<4, 2, FO, FI>(k, splits, s);
   return SFK_OK;
 }
 
 template <typename T>
-int launch(const sfk_wgrad_desc* d, hipStream_t s) {
+int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   WgradK k;
   k.x = d->x.ptr; k.dy = d->dy.ptr; k.dw = d->dw;
   k.xt = d->x.t; k.xh = d->x.h; k.xw = d->x.w; k.xld = d->x.ld; k.xoff = d->x.c_off;
@@ -486,23 +586,33 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s) {
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.dbytes = (uint32_t)sfk_fmap_bytes(&d->dy);
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
+  static const int use_ws = getenv("SFK_WGWS") ? atoi(getenv("SFK_WGWS")) : 1;   // A/B knob
+  k.ws = use_ws ? reinterpret_cast<float4*>(d->workspace) : nullptr;
   const int cols = d->ntaps * d->cin;
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
-    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s);
-    return launch_dma<128, 4>(k, d, s);
+    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s, dry);
+    return launch_dma<128, 4>(k, d, s, dry);
   }
   if (cols <= 32) {
-    if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s);
-    if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s);
-    return launch_cfg<T, 128, 32, 2>(k, d, s);
+    if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s, dry);
+    if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s, dry);
+    return launch_cfg<T, 128, 32, 2>(k, d, s, dry);
   }
-  if (d->cout <= 32) return launch_cfg<T, 32, 128, 2>(k, d, s);
-  if (d->cout <= 64) return launch_cfg<T, 64, 128, 2>(k, d, s);
-  return launch_cfg<T, 128, 128, 1>(k, d, s);
+  if (d->cout <= 32) return launch_cfg<T, 32, 128, 2>(k, d, s, dry);
+  if (d->cout <= 64) return launch_cfg<T, 64, 128, 2>(k, d, s, dry);
+  return launch_cfg<T, 128, 128, 1>(k, d, s, dry);
 }
 
 }  // namespace
+
+extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
+  const int st = validate(d);
+  if (st != SFK_OK) return st;
+  int64_t bytes = 0;
+  const int r = d->x.dtype == SFK_BF16 ? launch<bf16_t>(d, nullptr, &bytes) : launch<float>(d, nullptr, &bytes);
+  return r != SFK_OK ? r : bytes;
+}
 
 extern "C" int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream) {
   const int st = validate(d);

@@ -400,8 +400,16 @@ class Engine:
     def _wgrad(self, pl: Plan, rec: _UnitRec, dy: FMap):
         L = rec.L
         esz = 2 if self.dtype == torch.bfloat16 else 4
-        pl.bwd.append(self.be.conv_wgrad(WgradPass(rec.x, dy, L.eg.s, list(wgrad_taps(L.eg)),
-                                                   self._gslice(L.w_off, L.w_numel), L.eg.wtaps, L.eg.cin, L.eg.cout)),
+        wp = WgradPass(rec.x, dy, L.eg.s, list(wgrad_taps(L.eg)), self._gslice(L.w_off, L.w_numel), L.eg.wtaps,
+                       L.eg.cin, L.eg.cout)
+        # scratch for the split sums: one buffer per pathway stream (launches on a stream are ordered), grown to the
+        # largest request; the descriptor keeps the pointer, so size it before binding
+        need = self.be.conv_wgrad_workspace_bytes(wp)
+        if need > 0:
+            cap = self._wg_ws_need.get(pl.bwd.cur_lane, 0)
+            self._wg_ws_need[pl.bwd.cur_lane] = max(cap, need)
+            self._wg_pending.append((pl.bwd, len(pl.bwd), wp, pl.bwd.cur_lane))
+        pl.bwd.append(self.be.conv_wgrad(wp),
                       kind="conv_wgrad", layer=L.cb.conv_key, cout=L.eg.cout,
                       flops=2.0 * dy.pixels * L.eg.cout * L.eg.cin * L.eg.wtaps,
                       bytes=float(esz * (rec.x.pixels * L.eg.cin + dy.pixels * L.eg.cout) + 4 * L.w_numel))
@@ -562,6 +570,7 @@ class Engine:
     def _build_plan(self, x_slow: torch.Tensor, x_fast: torch.Tensor, slow_t_index, train: bool) -> Plan:
         be, spec, W = self.be, self.spec, self.wiring
         pl = Plan()
+        self._wg_ws_need, self._wg_pending = {}, []
         n = x_fast.shape[0]
         # ---- refresh the compute-precision filter copies from the fp32 master arena
         #      (one launch: cast into the forward layout and, for training, the data-gradient transposes)
@@ -690,6 +699,11 @@ class Engine:
         self._stem_bwd(pl, 1, stem_recs[1], d_xf)
         B_.sync(0, 1)                                   # join before the optimiser
         B_.cur_lane = 0
+        # bind the filter-gradient ops to their lane's scratch now that its size is known
+        for oplist, slot, wp, lane in self._wg_pending:
+            wp.workspace = self._buf(f"wgws.{lane}", (self._wg_ws_need[lane] + 3) // 4, torch.float32)
+            oplist[slot] = self.be.conv_wgrad(wp)
+        self._wg_pending = []
         return pl
 
     # ------------------------------------------------------------------ execution
