@@ -288,6 +288,38 @@ int sfk_filter_refresh(const float* master, void* s, void* st, int32_t dtype, co
                        int32_t n_layers, int32_t total_blocks, sfk_stream_t stream);
 int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Either side of the hot path.
+ *
+ * sfk_u8_normalize_crop -- the dataset's per-frame preprocessing on device, so clips cross PCIe as uint8:
+ * transforms.ToTensor + Normalize(0.45, 0.225) (dataset/chalearn_dataset.py:41-46) and, for training,
+ * RandomCrop(size, padding = size // 10) (:73-85), one crop offset per clip.
+ *   src: uint8 [n][t][h][w][c] (the HWC `img_cat` frames of :113-114 stacked); lut: float[256] = the value
+ *   ((u/255) - 0.45)/0.225 of every byte, computed by the caller in fp32 exactly as the reference transforms do;
+ *   crop: device int32 [n][2] = (top, left) in [0, 2*pad], or NULL for no augmentation (test / valid clips);
+ *   out[n][t][ch][y][x] = lut[src[n][t][y + top - pad][x + left - pad][ch]], 0 outside the frame (RandomCrop pads
+ *   the normalised tensor with zeros); out dtype f32 (reference) or bf16.  The result is the (N,T,21,S,S) batch
+ *   tensor train.py:125-145 slices, laid out as the stems read it. */
+int sfk_u8_normalize_crop(const uint8_t* src, const float* lut, const int32_t* crop, int32_t pad, void* out,
+                          int32_t out_dtype, int32_t n, int32_t t, int32_t c, int32_t h, int32_t w,
+                          sfk_stream_t stream);
+
+/* sfk_eval_aggregate -- Trainer.run_eval's score aggregation (train.py:337-362) on device: per clip softmax
+ * (train.py:338; softmax = 0 keeps the scores as they are, as train_sparse.py:211-228 does), per video the mean over
+ * its clips (rows seg_off[v] .. seg_off[v+1]-1), argmax (first maximum), compared with the label of its first clip.
+ * ps_out (optional) [rows][c]; pred[v] = argmax or -1 for a video without clips; *correct += #(pred == label). */
+int sfk_eval_aggregate(const float* logits, const int64_t* labels, const int32_t* seg_off, int32_t nvideos, int32_t c,
+                       int32_t softmax, float* ps_out, int32_t* pred, int32_t* correct, sfk_stream_t stream);
+
+/* SparseModel of the late-fusion ensemble (train_sparse.py:88-104): one nn.Linear(num_part, 1) per class,
+ *   y[n][k] = b[k] + sum_p w[k][p] * x[n][p][k],   x = (N, P, C) stacked part scores, w = fcs.k.weight (1, P) rows.
+ * bwd ACCUMULATES dw[k][p] += sum_n dy[n][k]*x[n][p][k], db[k] += sum_n dy[n][k] (CrossEntropyLoss / Adam of
+ * train_sparse.py:157-158,171-176 are sfk_softmax_ce / sfk_adam). */
+int sfk_sparse_fusion_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t p, int32_t c,
+                          sfk_stream_t stream);
+int sfk_sparse_fusion_bwd(const float* x, const float* dy, float* dw, float* db, int32_t n, int32_t p, int32_t c,
+                          sfk_stream_t stream);
+
 int sfk_abi_version(void);
 const char* sfk_status_string(int status);
 

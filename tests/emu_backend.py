@@ -414,6 +414,47 @@ class EmuBackend:
             dst[:count].copy_(src[:count])
         return run
 
+    # ------------------------------------------------------------------ rows either side of the hot path
+    def u8_normalize_crop(self, src_u8, lut, crop, pad, out):
+        def run(stream):
+            n, t, h, w, c = src_u8.shape
+            x = lut[src_u8.long()].permute(0, 1, 4, 2, 3)                         # (n,t,c,h,w) fp32
+            if crop is None:
+                out.copy_(x)
+                return
+            xp = torch.nn.functional.pad(x, (pad, pad, pad, pad))
+            for i in range(n):
+                oy, ox = int(crop[i, 0]), int(crop[i, 1])
+                out[i] = xp[i, :, :, oy:oy + h, ox:ox + w]
+        return run
+
+    def eval_aggregate(self, logits, labels, seg_off, nvideos, softmax, ps_out, pred, correct):
+        def run(stream):
+            ps = torch.softmax(logits, dim=1) if softmax else logits
+            if ps_out is not None:
+                ps_out.copy_(ps)
+            for v in range(nvideos):
+                r0, r1 = int(seg_off[v]), int(seg_off[v + 1])
+                if r1 <= r0:
+                    pred[v] = -1
+                    continue
+                k = int(torch.argmax(ps[r0:r1].sum(0) / (r1 - r0)))
+                pred[v] = k
+                if correct is not None and k == int(labels[r0]):
+                    correct += 1
+        return run
+
+    def sparse_fusion_fwd(self, x, w, b, y, n, p, c):
+        def run(stream):
+            y.copy_(torch.einsum("npc,cp->nc", x, w.view(c, p)) + b)
+        return run
+
+    def sparse_fusion_bwd(self, x, dy, dw, db, n, p, c):
+        def run(stream):
+            dw.view(c, p).add_(torch.einsum("nc,npc->cp", dy, x))
+            db.add_(dy.sum(0))
+        return run
+
     def fill_zero(self, t):
         def run(stream):
             t.zero_()

@@ -200,6 +200,10 @@ SIGNATURES = {
     "sfk_filter_transpose": [_PV, _I32, _PV, _I32, _I32, _I32, _I32, _PV],
     "sfk_cast": [_PV, _I32, _PV, _I32, _I64, _PV],
     "sfk_fill_zero": [_PV, C.c_size_t, _PV],
+    "sfk_u8_normalize_crop": [_PV, _PF, _PV, _I32, _PV, _I32, _I32, _I32, _I32, _I32, _I32, _PV],
+    "sfk_eval_aggregate": [_PF, _PV, _PV, _I32, _I32, _I32, _PF, _PV, _PV, _PV],
+    "sfk_sparse_fusion_fwd": [_PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
+    "sfk_sparse_fusion_bwd": [_PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
     "sfk_filter_refresh": [_PF, _PV, _PV, _I32, _PV, _I32, _I32, _PV],
     "sfk_abi_version": [],
     "sfk_status_string": [C.c_int],
@@ -505,6 +509,25 @@ class HipBackend:
         ref = st if st is not None else s
         return self._plain("sfk_filter_refresh", _ptr(master), _ptr(s), _ptr(st), _DT[ref.dtype], _ptr(table),
                            len(layers), fb, keep=(master, s, st, table))
+
+    def u8_normalize_crop(self, src_u8, lut, crop, pad: int, out):
+        """src_u8 (N,T,H,W,C) uint8 -> out (N,T,C,H,W) f32|bf16 = lut[byte], shifted by the per-clip crop (or None)"""
+        n, t, h, w, c = src_u8.shape
+        assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and out.is_contiguous()
+        assert tuple(out.shape) == (n, t, c, h, w)
+        return self._plain("sfk_u8_normalize_crop", _ptr(src_u8), _ptr(lut), _ptr(crop), pad, _ptr(out), _DT[out.dtype],
+                           n, t, c, h, w, keep=(src_u8, lut, crop, out))
+
+    def eval_aggregate(self, logits, labels, seg_off, nvideos: int, softmax: bool, ps_out, pred, correct):
+        return self._plain("sfk_eval_aggregate", _ptr(logits), _ptr(labels), _ptr(seg_off), nvideos, logits.shape[1],
+                           1 if softmax else 0, _ptr(ps_out), _ptr(pred), _ptr(correct),
+                           keep=(logits, labels, seg_off, ps_out, pred, correct))
+
+    def sparse_fusion_fwd(self, x, w, b, y, n, p, c):
+        return self._plain("sfk_sparse_fusion_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, p, c, keep=(x, w, b, y))
+
+    def sparse_fusion_bwd(self, x, dy, dw, db, n, p, c):
+        return self._plain("sfk_sparse_fusion_bwd", _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, p, c, keep=(x, dy, dw, db))
 
     def fill_zero(self, t: torch.Tensor):
         return self._plain("sfk_fill_zero", t.data_ptr(), t.numel() * t.element_size(), keep=(t,))

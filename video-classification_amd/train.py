@@ -117,6 +117,7 @@ class ModelManager:
 
     def __init__(self, cfg, device="cuda", backend=None):
         self.cfg, self.device, self.backend = cfg, device, backend
+        self._pre = None
         name = cfg.MODEL.NAME
         if "slowfast" in name:
             self.init_model = self._init_slowfast_model
@@ -148,8 +149,17 @@ class ModelManager:
 
     def _prepare_slowfast_data(self, batch):
         """(N,T,21,S,S) -> [BGR+UV (N,5,T,S,S), flow (N,15,T,S,S)] strided views of the SAME memory; the depth channel
-        (20) is dropped (train.py:125-145).  The stem kernels read these views in place."""
-        x = batch[self.cfg.MODEL.R3D_INPUT].to(self.device, non_blocking=True)
+        (20) is dropped (train.py:125-145).  The stem kernels read these views in place.
+        A batch that carries ``<R3D_INPUT>_u8`` (N,T,S,S,21 uint8 frames, optional ``crop`` (N,2)) instead of the float32
+        tensor takes the uint8 transport: normalise + RandomCrop run on the device (input_pipeline.py)."""
+        key = self.cfg.MODEL.R3D_INPUT
+        if key + "_u8" in batch:
+            if self._pre is None:
+                from .input_pipeline import DevicePreprocess
+                self._pre = DevicePreprocess(self.device, self.backend)
+            x = self._pre(batch[key + "_u8"], batch.get("crop"))
+        else:
+            x = batch[key].to(self.device, non_blocking=True)
         x = torch.permute(x, [0, 2, 1, 3, 4])
         y_true = batch['label'].to(self.device, non_blocking=True)
         return [x[:, 0:5], x[:, 5:20]], y_true
@@ -159,8 +169,10 @@ class SyntheticChalearn(torch.utils.data.Dataset):
     """Stand-in with the item contract of the reference's ChalearnVideoDataset (dataset/chalearn_dataset.py:162-185):
     train -> dict, test -> list of dicts (uniform windows), values normalised like ToTensor+Normalize(0.45, 0.225)."""
 
-    def __init__(self, cfg, name_of_set: str, num_videos: int = 8, clips_per_video=(1, 3), seed: int = 0):
+    def __init__(self, cfg, name_of_set: str, num_videos: int = 8, clips_per_video=(1, 3), seed: int = 0,
+                 as_uint8: bool = False):
         self.cfg, self.name = cfg, name_of_set
+        self.as_uint8 = as_uint8          # hand over the HWC uint8 frames (+ the train clip's crop offsets) instead
         self.key = cfg.MODEL.R3D_INPUT
         self.size = crop_resize_dict[self.key]
         self.t = cfg.CHALEARN.CLIP_LEN
@@ -175,6 +187,12 @@ class SyntheticChalearn(torch.utils.data.Dataset):
     def _clip(self, i, j):
         g = torch.Generator().manual_seed(self.seed * 7919 + i * 31 + j)
         u8 = torch.randint(0, 256, (self.t, 21, self.size, self.size), generator=g, dtype=torch.uint8)
+        if self.as_uint8:
+            item = {self.key + "_u8": u8.permute(0, 2, 3, 1).contiguous(), 'label': self.labels[i]}
+            if self.name == 'train':
+                from .input_pipeline import draw_crop_offsets
+                item['crop'] = draw_crop_offsets(1, self.size // 10, g)[0]
+            return item
         return {self.key: (u8.float() / 255.0 - 0.45) / 0.225, 'label': self.labels[i]}
 
     def __getitem__(self, i):
@@ -276,17 +294,20 @@ class Trainer:
 
     def run_eval(self, dataset_loader=None):
         """Batched no-grad forward over uniform windows; softmax; per-video mean over its clips; argmax
-        (train.py:287-370).  Returns {'ps','t','acc','sv'} as train_sparse.py:76-84 consumes it."""
+        (train.py:287-370).  Returns {'ps','t','acc','sv'} as train_sparse.py:76-84 consumes it.
+        The logits of every batch stay on the device; softmax, the per-video mean, argmax and the accuracy count are
+        ONE ``sfk_eval_aggregate`` launch at the end, followed by one device->host copy of the result (the reference
+        copies logits and labels to the host after every batch, train.py:308-309)."""
         loader = self.test_loader if dataset_loader is None else dataset_loader
-        pred_score_list, true_list, batch_collect, samples_per_video = [], [], [], []
+        logit_list, true_list, batch_collect, samples_per_video = [], [], [], []
         self.model.eval()
 
         def test_batch(collect):
             x, y_true = self.mm.prepare_data(collect)
             with torch.no_grad():
                 y_pred = self.model(x)
-            pred_score_list.append(y_pred.float().cpu().numpy())
-            true_list.append(y_true.cpu().numpy())
+            logit_list.append(y_pred.float().clone())      # the engine reuses its logits buffer
+            true_list.append(y_true.clone())
 
         for step, batch in enumerate(loader):
             for b in batch:
@@ -301,19 +322,30 @@ class Trainer:
                 break
         if len(batch_collect) > 0:
             test_batch(default_collate(batch_collect))
-        ps = np.concatenate(pred_score_list, axis=0)
-        ps = np.exp(ps) / np.sum(np.exp(ps), axis=1, keepdims=True)
-        true_arr = np.concatenate(true_list, axis=0)
-        correct_list, read_index = [], 0
-        for num_samples in samples_per_video:
-            preds = ps[read_index: read_index + num_samples]
-            trues = true_arr[read_index: read_index + num_samples]
-            read_index += num_samples
-            if len(preds) == 0:
-                continue
-            assert np.all(trues == trues[0])
-            correct_list.append(np.argmax(np.mean(preds, axis=0), axis=0) == trues[0])
-        c = np.array(correct_list)
-        accuracy = c.sum() / max(len(c), 1)
-        print(f'Test Accuracy: {round(float(accuracy), 3)}. ({c.sum()} / {len(c)})')
+        logits = torch.cat(logit_list, dim=0).contiguous()
+        labels = torch.cat(true_list, dim=0).to(torch.int64).contiguous()
+        ps, pred, ncorrect = aggregate_scores(self.model.engine.be, logits, labels, samples_per_video, softmax=True)
+        ps, true_arr = ps.cpu().numpy(), labels.cpu().numpy()
+        nvid = sum(1 for s_ in samples_per_video if s_ > 0)
+        accuracy = ncorrect / max(nvid, 1)
+        print(f'Test Accuracy: {round(float(accuracy), 3)}. ({ncorrect} / {nvid})')
         return {'ps': ps, 't': true_arr, 'acc': accuracy, 'sv': samples_per_video}
+
+
+def aggregate_scores(be, scores: torch.Tensor, labels: torch.Tensor, samples_per_video, softmax: bool):
+    """(ps, pred per video, #correct videos) through sfk_eval_aggregate; scores (rows, classes) fp32 on the device.
+    Videos without clips are skipped, as the reference loops do (train.py:351-362, train_sparse.py:211-228)."""
+    dev = scores.device
+    seg = [0]
+    for s_ in samples_per_video:
+        seg.append(seg[-1] + int(s_))
+    assert seg[-1] <= scores.shape[0]
+    seg_off = torch.tensor(seg, dtype=torch.int32).to(dev)
+    nvid = len(samples_per_video)
+    ps = torch.empty_like(scores)
+    pred = torch.empty(max(nvid, 1), dtype=torch.int32, device=dev)
+    correct = torch.zeros(1, dtype=torch.int32, device=dev)
+    if nvid > 0:
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        be.eval_aggregate(scores, labels, seg_off, nvid, softmax, ps, pred, correct)(stream)
+    return ps, pred[:nvid], int(correct[0])
