@@ -28,6 +28,7 @@ struct ConvK {
   int cin, cout, wtaps, ntaps, KC, accumulate;
   int mtiles, ntiles;
   int wide_store;   // bf16 output with 16-byte addressable 8-channel groups
+  int lin_out;      // output pixel index == row index (os = 1, oo = 0, row extents = y extents)
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
@@ -119,6 +120,15 @@ __device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, 
   *reinterpret_cast<bf16x8*>(p) = o;
 }
 __device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool) {}   // f32 stores are 16 B already
+
+// 16-lane row sum with DPP shifts (4 VALU ops; __shfl_xor goes through ds_bpermute): the total ends in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  return v;
+}
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
@@ -270,12 +280,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
     if (m < k.M) {
-      uint32_t q1, rw_, q2, rh_, n_, rt_;
-      k.drw.divmod((uint32_t)m, q1, rw_);
-      k.drh.divmod(q1, q2, rh_);
-      k.drt.divmod(q2, n_, rt_);
-      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-      const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      int64_t poff;
+      if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
+        poff = (int64_t)m * k.yld + k.yoff;
+      } else {
+        uint32_t q1, rw_, q2, rh_, n_, rt_;
+        k.drw.divmod((uint32_t)m, q1, rw_);
+        k.drh.divmod(q1, q2, rh_);
+        k.drt.divmod(q2, n_, rt_);
+        const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+        poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      }
       if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
@@ -304,12 +319,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
           s1 += v;
           s2 += v * v;
         }
-#pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) {
-          s1 += __shfl_xor(s1, sft);
-          s2 += __shfl_xor(s2, sft);
-        }
-        if (l15 == 0) {
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (l15 == 15) {
           const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
           red[(wm * BN + col) * 2 + 0] = s1;
           red[(wm * BN + col) * 2 + 1] = s2;
@@ -542,12 +554,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
     if (m < k.M) {
-      uint32_t q1, rw_, q2, rh_, n_, rt_;
-      k.drw.divmod((uint32_t)m, q1, rw_);
-      k.drh.divmod(q1, q2, rh_);
-      k.drt.divmod(q2, n_, rt_);
-      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-      const int64_t poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      int64_t poff;
+      if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
+        poff = (int64_t)m * k.yld + k.yoff;
+      } else {
+        uint32_t q1, rw_, q2, rh_, n_, rt_;
+        k.drw.divmod((uint32_t)m, q1, rw_);
+        k.drh.divmod(q1, q2, rh_);
+        k.drt.divmod(q2, n_, rt_);
+        const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+        poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+      }
       if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
@@ -574,12 +591,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
           s1 += v;
           s2 += v * v;
         }
-#pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) {
-          s1 += __shfl_xor(s1, sft);
-          s2 += __shfl_xor(s2, sft);
-        }
-        if (l15 == 0) {
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (l15 == 15) {
           const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
           red[(wm * BN + col) * 2 + 0] = s1;
           red[(wm * BN + col) * 2 + 1] = s2;
@@ -665,6 +679,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dspt.set(d->cin / vec);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  k.lin_out = d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
+              d->rt == d->y.t && d->rh == d->y.h && d->rw == d->y.w;
   static const int wide_ok = getenv("SFK_WIDE") ? atoi(getenv("SFK_WIDE")) : 1;   // A/B knob
   k.wide_store = wide_ok && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
