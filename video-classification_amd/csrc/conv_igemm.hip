@@ -28,6 +28,7 @@ struct ConvK {
   int cin, cout, wtaps, ntaps, KC, accumulate;
   int mtiles, ntiles;
   int wide_store;   // bf16 output with 16-byte addressable 8-channel groups
+  int kshort;       // K-step count up to which the exact-count K loop runs
   int lin_out;      // output pixel index == row index (os = 1, oo = 0, row extents = y extents)
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
@@ -130,7 +131,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool SHORTK>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
   using TL = Tile<T>;
   constexpr int VEC = TL::VEC, SEGS = TL::SEGS, ROWB = TL::ROWB;
@@ -256,21 +257,62 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   // it&1, the tile of step it+1 waits in one register set and the loads of step it+2 are in flight in the other.
   // K-steps past the end gather nothing (every slot is SFK_OOB -> zeros), so the body runs unconditionally for an even
   // number of steps: no guards around the loads means the compiler counts them exactly (vmcnt(N), never a full drain).
-  const int nit2 = (k.KC + 1) & ~1;
+  // Layers with at most k.kshort K-steps run the SHORTK instantiation instead: an exact-count loop (its guards cost the
+  // steady loop its exact vmcnt, which does not matter for a handful of steps); the rounded-up look-ahead loop spent up
+  // to 3/4 of a short layer's gather instructions on steps that load nothing.  Two instantiations, not one kernel
+  // with both loops: together they spill.
   Stage r0, r1;
-  gload(0, r0);
-  lstore(0, r0);
-  gload(1, r1);
-  __syncthreads();
-  for (int it = 0; it < nit2; it += 2) {
-    gload(it + 2, r0);
-    compute(0);
-    lstore(1, r1);
-    __syncthreads();
-    gload(it + 3, r1);
-    compute(1);
+  if constexpr (SHORTK) {
+    // short K (1..5 steps: the fast pathway's 8..64-channel layers): exact step count, nothing loaded past the end
+    gload(0, r0);
     lstore(0, r0);
+    if (k.KC > 1) gload(1, r1);
     __syncthreads();
+    int it = 0;
+    for (; it + 3 < k.KC; it += 2) {
+      gload(it + 2, r0);
+      compute(0);
+      lstore(1, r1);
+      __syncthreads();
+      gload(it + 3, r1);
+      compute(1);
+      lstore(0, r0);
+      __syncthreads();
+    }
+    const int rem = k.KC - it;            // 1, 2 or 3 steps left; LDS buffer 0 holds step `it`, r1 step it+1
+    if (rem == 1) {
+      compute(0);
+    } else if (rem == 2) {
+      compute(0);
+      lstore(1, r1);
+      __syncthreads();
+      compute(1);
+    } else {
+      gload(it + 2, r0);
+      compute(0);
+      lstore(1, r1);
+      __syncthreads();
+      compute(1);
+      lstore(0, r0);
+      __syncthreads();
+      compute(0);
+    }
+  } else {
+    const int nit2 = (k.KC + 1) & ~1;
+    gload(0, r0);
+    lstore(0, r0);
+    gload(1, r1);
+    __syncthreads();
+    for (int it = 0; it < nit2; it += 2) {
+      gload(it + 2, r0);
+      compute(0);
+      lstore(1, r1);
+      __syncthreads();
+      gload(it + 3, r1);
+      compute(1);
+      lstore(0, r0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
@@ -307,7 +349,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 
   // ---- BatchNorm partial statistics of this tile (rows past M accumulated zeros, so they add nothing)
   if (k.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; all LDS reads of the K loop are behind a barrier
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2], aliases the ring: wait for the last K-step's LDS reads
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
 #pragma unroll
@@ -679,6 +722,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dspt.set(d->cin / vec);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  static const int kshort = getenv("SFK_KSHORT") ? atoi(getenv("SFK_KSHORT")) : 5;   // A/B knob
+  k.kshort = kshort;
   k.lin_out = d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
               d->rt == d->y.t && d->rh == d->y.h && d->rw == d->y.w;
   static const int wide_ok = getenv("SFK_WIDE") ? atoi(getenv("SFK_WIDE")) : 1;   // A/B knob
@@ -695,10 +740,15 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
     if (k.xbytes < 0x7FF00000u && k.wbytes < 0x7FF00000u) return launch_dma(k, ts.bm, grid, s);
     return SFK_ERR_UNSUPPORTED;   // the DMA path addresses < 2 GiB per operand
   }
-  if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, k);
-  else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1>), grid, block, 0, s, k);
-  else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1>), grid, block, 0, s, k);
-  else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1>), grid, block, 0, s, k);
+  if (k.KC <= k.kshort && ts.bn <= 32) {   // (the wider tiles spill with the exact-count loop: 124..228 B per lane)
+    if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, true>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1, true>), grid, block, 0, s, k);
+  } else {
+    if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false>), grid, block, 0, s, k);
+    else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false>), grid, block, 0, s, k);
+    else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1, false>), grid, block, 0, s, k);
+  }
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
