@@ -275,8 +275,8 @@ int sfk_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, i
  *     s [off + i]                           = (dtype) master[off + i]                     (skipped when s  == NULL)
  *     st[off + (ci*wtaps + tap)*cout + co]  = (dtype) master[off + (co*wtaps + tap)*cin + ci]   (entries with
  *                                             transpose != 0; skipped when st == NULL)
- * `table` is DEVICE memory; entry e owns blocks [first_block, first_block + ceil(cout*wtaps*cin / 2048)), ascending,
- * and total_blocks is their sum. */
+ * `table` is DEVICE memory; entry e owns the wtaps * ceil(cout/32) * ceil(cin/32) blocks from first_block on (one
+ * 32 x 32 (co, ci) tile of one tap each), ascending, and total_blocks is their sum. */
 typedef struct {
   int64_t off;
   int32_t cout, wtaps, cin;

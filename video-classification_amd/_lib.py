@@ -504,7 +504,7 @@ class HipBackend:
         fb = 0
         for i, (off, cout, wtaps, cin, tr) in enumerate(layers):
             ent[i] = (off, cout, wtaps, cin, fb, 1 if tr else 0, 0)
-            fb += (cout * wtaps * cin + 2047) // 2048
+            fb += wtaps * ((cout + 31) // 32) * ((cin + 31) // 32)
         table = torch.from_numpy(ent.view(np.uint8).copy()).to(master.device)
         ref = st if st is not None else s
         return self._plain("sfk_filter_refresh", _ptr(master), _ptr(s), _ptr(st), _DT[ref.dtype], _ptr(table),

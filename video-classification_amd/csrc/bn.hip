@@ -104,28 +104,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(FM y, int64_t pixels, int
 // 50,176 x 8), so the fold is split: bn_fold_kernel reduces `nparts` rows to <= SFK_BN_FOLD_ROWS rows with coalesced
 // reads (64 adjacent channels per wave-row = 512 B), then one wave per channel folds those in the finalize kernel.
 // Both levels accumulate in double and in a fixed order: deterministic, no atomics.
+// block = (256 / cw) row lanes x cw channel lanes, cw = min(64, c rounded up to a power of two): the narrow maps of the
+// fast pathway (8..32 channels, up to 50,176 rows) keep all 256 threads busy instead of c of every 64.
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ partials, int nparts, int c, int per,
-                                                      float* __restrict__ out) {
-  __shared__ double red[2][4][64];
-  const int tx = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int ch = blockIdx.y * 64 + tx;
+                                                      float* __restrict__ out, int cw) {
+  __shared__ double red[2][256];
+  const int nrl = 256 / cw;
+  const int tx = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int ch = blockIdx.y * cw + tx;
   const int r0 = blockIdx.x * per;
   int r1 = r0 + per;
   if (r1 > nparts) r1 = nparts;
   double s1 = 0.0, s2 = 0.0;
   if (ch < c) {
-    for (int p = r0 + rl; p < r1; p += 4) {
+    for (int p = r0 + rl; p < r1; p += nrl) {
       const float2 v = *reinterpret_cast<const float2*>(partials + ((int64_t)p * c + ch) * 2);
       s1 += (double)v.x;
       s2 += (double)v.y;
     }
   }
-  red[0][rl][tx] = s1;
-  red[1][rl][tx] = s2;
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
   __syncthreads();
   if (rl == 0 && ch < c) {
-    const double a = ((red[0][0][tx] + red[0][1][tx]) + red[0][2][tx]) + red[0][3][tx];
-    const double b = ((red[1][0][tx] + red[1][1][tx]) + red[1][2][tx]) + red[1][3][tx];
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < nrl; ++r) {          // fixed order: deterministic
+      a += red[0][r * cw + tx];
+      b += red[1][r * cw + tx];
+    }
     *reinterpret_cast<float2*>(out + ((int64_t)blockIdx.x * c + ch) * 2) = make_float2((float)a, (float)b);
   }
 }
@@ -139,7 +145,9 @@ inline const float* fold_partials(const float* partials, int nparts, int c, floa
   }
   const int per = (nparts + SFK_BN_FOLD_ROWS - 1) / SFK_BN_FOLD_ROWS;
   const int rows = (nparts + per - 1) / per;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(rows, (c + 63) / 64), dim3(256), 0, s, partials, nparts, c, per, workspace);
+  int cw = 8;
+  while (cw < c && cw < 64) cw <<= 1;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(rows, (c + cw - 1) / cw), dim3(256), 0, s, partials, nparts, c, per, workspace, cw);
   *rows_out = rows;
   return workspace;
 }
