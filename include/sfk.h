@@ -82,6 +82,22 @@ typedef struct {
  * Requirements: x.dtype == y.dtype; cin % (16/sizeof(dtype)) == 0, likewise x.ld, x.c_off; cout % 4 == 0,
  *   y.ld % 4 == 0, y.c_off % 4 == 0; 16-byte aligned base pointers.
  */
+/* Optional fusion of the BatchNorm-backward REDUCE into a data-gradient pass (autograd of conv -> BatchNorm3d -> ReLU
+ * chains, train.py:230): when the pass's output Y is dA, the gradient w.r.t. the activation a = act(bn(y_bn) [+ shortcut]),
+ * the epilogue stores  dz = result * mask  (mask as sfk_bn_bwd_reduce: (mask_src > 0) if mask_src.ptr, else
+ * (y_bn*scale + shift > 0) if relu, else 1) instead of dA, and writes the partial rows
+ *     partials[tile][cout][2] = (sum dz, sum dz * x_hat),  x_hat = (y_bn - mean) * invstd,  tile < sfk_conv_igemm_mtiles(d)
+ * for sfk_bn_bwd_finalize -- sfk_bn_bwd_reduce's result without its three tensor reads and one write.
+ * y_bn / mask_src share Y's pixel grid and channel count (own ld / c_off).  partials == NULL: off.
+ * Supported when sfk_conv_bnb_supported(d) != 0 (bf16, 8-channel groups 16-byte addressable, cout > 16). */
+typedef struct {
+  sfk_fmap y_bn;
+  sfk_fmap mask_src; /* ptr == NULL: none */
+  const float *mean, *invstd, *scale, *shift;
+  int32_t relu;
+  float* partials;
+} sfk_bn_bwd_fuse;
+
 typedef struct {
   sfk_fmap x, y;
   int32_t rt, rh, rw;
@@ -92,10 +108,12 @@ typedef struct {
   int32_t wtaps, cin, cout;
   int32_t accumulate;
   float* stats;
+  sfk_bn_bwd_fuse bnb;
 } sfk_conv_desc;
 
 int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream);
-int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats; <0 on error */
+int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats / d->bnb.partials; <0 on error */
+int sfk_conv_bnb_supported(const sfk_conv_desc* d);  /* 1 if d (ignoring d->bnb) can run with the bnb fusion, else 0 */
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_conv_wgrad -- Conv3d filter gradient (autograd of the same nn.Conv3d modules, train.py:230).

@@ -95,6 +95,9 @@ class EmuBackend:
     def conv_wgrad_workspace_bytes(self, p) -> int:
         return 0
 
+    def conv_bnb_supported(self, p) -> bool:
+        return False          # the emulation keeps the stand-alone BatchNorm-backward reduce
+
     def conv_wgrad(self, p: WgradPass):
         def run(stream):
             X = p.x.view5().float()

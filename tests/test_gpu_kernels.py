@@ -473,3 +473,62 @@ def test_filter_refresh_one_launch(hip, dtype):
     hip.filter_refresh(master.to(DEV), None, st2, layers)(stream())
     torch.cuda.synchronize()
     assert torch.equal(st2.cpu(), wst)
+
+
+BNB_CASES = [
+    # cin (of the pass), cout (channels of dA), taps/geometry as a forward conv descriptor, dims, accumulate, mask mode
+    (64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 24, 28), True, "mask_src"),     # identity-shortcut data gradient
+    (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 8, 72, 60), False, "relu"),        # 256x128 DMA tile? no: cout 64 -> 256x64
+    (128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 20, 22), False, "relu"),       # 3x3, 128x128 DMA tile
+    (64, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 9, 11), False, "relu"),          # narrow: 256x32 tile, ragged M
+    (512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 48, 48), True, "none"),        # M = 36864: 256x128 DMA tile
+]
+
+
+@pytest.mark.parametrize("case", BNB_CASES, ids=[f"c{c[0]}-{c[1]}-{c[7]}-acc{int(c[6])}" for c in BNB_CASES])
+def test_conv_fused_bn_backward_reduce(hip, case):
+    """sfk_conv_desc.bnb: the pass that produces dA stores dz = dA * mask and leaves (sum dz, sum dz*x_hat) partial rows
+    == the plain pass followed by sfk_bn_bwd_reduce (dz bit for bit, the folded sums to fp32 accuracy)."""
+    from video_classification_amd._lib import BnBwdFuse
+    cin, cout, k, s, p, (n, t, h, w), accumulate, mode = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(31 + cin + cout)
+    g = ConvGeom(cin, cout, k, s, p)
+    od = g.out_dims((t, h, w))
+    sp = fwd_pass(g, (t, h, w))
+    _, xg = fmap_pair(n, cin, t, h, w, dtype, gen)
+    wgt = mk((cout * g.wtaps * cin,), dtype, gen, (g.wtaps * cin) ** -0.5).to(DEV)
+    base = mk((n * od[0] * od[1] * od[2] * (cout + 8),), dtype, gen)                  # dA buffer (accumulated into), slice of a wider record
+    _, ybn = fmap_pair(n, cout, *od, dtype, gen)
+    _, msk = fmap_pair(n, cout, *od, dtype, gen, ld=cout + 8, c_off=8)
+    mean, invstd = (torch.randn(cout, generator=gen) * 0.2).to(DEV), (torch.rand(cout, generator=gen) + 0.5).to(DEV)
+    scale, shift = (torch.randn(cout, generator=gen)).to(DEV), (torch.randn(cout, generator=gen) * 0.3).to(DEV)
+    mask_src = msk if mode == "mask_src" else None
+    relu = mode != "none"
+
+    def dA():
+        return FMap(base.clone().to(DEV), n, *od, cout, cout + 8, 0)
+    # reference: plain pass, then the stand-alone reduce writing dz in place
+    ya = dA()
+    hip.conv_igemm(ConvPass(xg, ya, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt, g.wtaps, cin, cout, accumulate=accumulate))(stream())
+    parts_a = torch.zeros(2048 * cout * 2, device=DEV)
+    run, npa = hip.bn_bwd_reduce(ya, ybn, mask_src, mean, invstd, scale, shift, relu, ya, parts_a, 2048)
+    run(stream())
+    # fused
+    yb = dA()
+    cp = ConvPass(xg, yb, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt, g.wtaps, cin, cout, accumulate=accumulate)
+    assert hip.conv_bnb_supported(cp)
+    mt = hip.conv_igemm_mtiles(cp)
+    parts_b = torch.full((mt * cout * 2,), float("nan"), device=DEV)
+    cp.bnb = BnBwdFuse(ybn, mask_src, mean, invstd, scale, shift, relu, parts_b)
+    hip.conv_igemm(cp)(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ya.buf.cpu().view(torch.int16), yb.buf.cpu().view(torch.int16))      # dz, and the untouched 8 pad channels
+    sa = parts_a[: npa * cout * 2].view(npa, cout, 2).double().sum(0).cpu()
+    sb = parts_b.view(mt, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(sb).all()
+    assert rel_err(sb[:, 0].float(), sa[:, 0].float()) < 1e-5 and rel_err(sb[:, 1].float(), sa[:, 1].float()) < 1e-5
+    # what is not supported says so
+    small = ConvPass(xg, FMap(torch.zeros(n * od[0] * od[1] * od[2] * 16, dtype=dtype, device=DEV), n, *od, 16), sp.rows, sp.gs,
+                     sp.os, sp.oo, list(sp.taps), wgt[: 16 * g.wtaps * cin], g.wtaps, cin, 16)
+    assert not hip.conv_bnb_supported(small)

@@ -72,6 +72,19 @@ Tap = Tuple[int, int, int, int]  # (dt, dh, dw, widx)
 
 
 @dataclass
+class BnBwdFuse:
+    """sfk_bn_bwd_fuse: the BatchNorm-backward reduce folded into the data-gradient pass that produces dA."""
+    y_bn: FMap                       # conv output the BatchNorm normalised
+    mask_src: Optional[FMap]         # activation whose sign is the ReLU mask, or None
+    mean: torch.Tensor
+    invstd: torch.Tensor
+    scale: Optional[torch.Tensor]
+    shift: Optional[torch.Tensor]
+    relu: bool
+    partials: torch.Tensor           # fp32 [mtiles][cout][2]
+
+
+@dataclass
 class ConvPass:
     x: FMap
     y: FMap
@@ -86,6 +99,7 @@ class ConvPass:
     cout: int
     accumulate: bool = False
     stats: Optional[torch.Tensor] = None  # fp32 [mtiles][cout][2]
+    bnb: Optional[BnBwdFuse] = None
 
 
 @dataclass
@@ -138,11 +152,16 @@ class _Tap(C.Structure):
     _fields_ = [("dt", C.c_int8), ("dh", C.c_int8), ("dw", C.c_int8), ("widx", C.c_uint8)]
 
 
+class _BnBwdFuse(C.Structure):
+    _fields_ = [("y_bn", _FMap), ("mask_src", _FMap), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int32), ("partials", C.c_void_p)]
+
+
 class _ConvDesc(C.Structure):
     _fields_ = [("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
                 ("gs", C.c_int32 * 3), ("os", C.c_int32 * 3), ("oo", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("w", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p)]
+                ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("bnb", _BnBwdFuse)]
 
 
 class _WgradDesc(C.Structure):
@@ -173,6 +192,7 @@ _P_FMAP = C.POINTER(_FMap)
 SIGNATURES = {
     "sfk_conv_igemm": [C.POINTER(_ConvDesc), _PV],
     "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
+    "sfk_conv_bnb_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
@@ -267,6 +287,15 @@ def _c_conv(p: ConvPass) -> _ConvDesc:
     d.wtaps, d.cin, d.cout = p.wtaps, p.cin, p.cout
     d.accumulate = 1 if p.accumulate else 0
     d.stats = _ptr(p.stats)
+    if p.bnb is not None:
+        b = p.bnb
+        d.bnb.y_bn = _c_fmap(b.y_bn)
+        if b.mask_src is not None:
+            d.bnb.mask_src = _c_fmap(b.mask_src)
+        d.bnb.mean, d.bnb.invstd = _ptr(b.mean), _ptr(b.invstd)
+        d.bnb.scale, d.bnb.shift = _ptr(b.scale), _ptr(b.shift)
+        d.bnb.relu = 1 if b.relu else 0
+        d.bnb.partials = _ptr(b.partials)
     return d
 
 
@@ -286,6 +315,10 @@ class HipBackend:
         if r < 0:
             _check(r, "sfk_conv_igemm_mtiles")
         return r
+
+    def conv_bnb_supported(self, p: ConvPass) -> bool:
+        """can this pass take a BnBwdFuse (sfk_conv_bnb_supported)?"""
+        return bool(self.lib.sfk_conv_bnb_supported(C.byref(_c_conv(p))))
 
     def conv_igemm(self, p: ConvPass):
         d, fn, keep = _c_conv(p), self.lib.sfk_conv_igemm, p

@@ -30,6 +30,12 @@ struct ConvK {
   int wide_store;   // bf16 output with 16-byte addressable 8-channel groups
   int kshort;       // K-step count up to which the exact-count K loop runs
   int lin_out;      // output pixel index == row index (os = 1, oo = 0, row extents = y extents)
+  // fused BatchNorm-backward reduce (sfk_conv_desc.bnb): the stored value becomes dz = result * mask
+  const void* bn_y;        // the conv output the BatchNorm normalised (same pixel grid as y)
+  const void* bn_mask;     // activation whose sign is the ReLU mask, or NULL
+  int bn_yld, bn_yoff, bn_mld, bn_moff, bn_relu;
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+  float* bn_parts;         // [mtiles][cout][2] = (sum dz, sum dz * x_hat) per row tile; NULL = fusion off
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
@@ -131,7 +137,112 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool SHORTK>
+
+// Fused BatchNorm-backward reduce (bf16, 16-byte channel groups, an even number of co fragments per wave).  The pass
+// that produces dA -- the data gradient into a BatchNorm'ed activation -- already holds the finished values in its
+// accumulators, so its epilogue applies the ReLU mask, stores dz instead of dA, and leaves the two per-channel sums the
+// BatchNorm backward needs (sum dz, sum dz * x_hat) as per-tile partial rows, exactly as the forward pass leaves its
+// statistics.  The stand-alone reduce kernel (read dA, read y, read the mask, write dz) disappears; the epilogue reads
+// y (and the mask source) for its own tile only.  Fragment pairs are processed one at a time so that only 8 channels'
+// coefficients are live.   `red` = WM x BN x 2 floats of LDS (aliases the ring; the caller has drained it).
+template <int FM, int FN, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&acc)[FN][FM], float* red, int mt, int nt,
+                                                int wm, int wn, int lane, int tid) {
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
+  const bf16_t* __restrict__ by = static_cast<const bf16_t*>(k.bn_y);
+  const bf16_t* __restrict__ bm = static_cast<const bf16_t*>(k.bn_mask);
+  const int co_w = nt * BN + wn * (BN / WN);
+#pragma unroll
+  for (int p = 0; p < FN; p += 2) {
+    const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);       // this lane's 8 channels after the swap
+    const bool cok = co < k.cout;
+    float ca[8], cb[8], cs[8], ch[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cok ? co + e : 0;
+      const float is = k.bn_invstd[c];
+      ca[e] = is;
+      cb[e] = -k.bn_mean[c] * is;                                   // x_hat = y * ca + cb
+      cs[e] = (k.bn_relu && !bm) ? k.bn_scale[c] : 0.f;
+      ch[e] = (k.bn_relu && !bm) ? k.bn_shift[c] : 1.f;             // no mask: y*0 + 1 > 0
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+      if (m < k.M) {
+        int64_t plin;
+        if (k.lin_out) {
+          plin = m;
+        } else {
+          uint32_t q1, rw_, q2, rh_, n_, rt_;
+          k.drw.divmod((uint32_t)m, q1, rw_);
+          k.drh.divmod(q1, q2, rh_);
+          k.drt.divmod(q2, n_, rt_);
+          const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+          plin = (((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo;
+        }
+        float v[8] = {acc[p][j][0], acc[p][j][1], acc[p][j][2], acc[p][j][3],
+                      acc[p + 1][j][0], acc[p + 1][j][1], acc[p + 1][j][2], acc[p + 1][j][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
+        if (cok) {
+          bf16_t* op = yp + plin * k.yld + k.yoff + co;
+          if (k.accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(op);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+          }
+          const bf16x8 yv = *reinterpret_cast<const bf16x8*>(by + plin * k.bn_yld + k.bn_yoff + co);
+          bf16x8 mv;
+          if (bm) mv = *reinterpret_cast<const bf16x8*>(bm + plin * k.bn_mld + k.bn_moff + co);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yf = (float)yv[e];
+            const bool keep = bm ? ((float)mv[e] > 0.f) : (yf * cs[e] + ch[e] > 0.f);
+            // dz is what the BatchNorm backward sees: the value as it is STORED (bf16), masked
+            const bf16_t dzb = (bf16_t)(keep ? v[e] : 0.f);
+            const float dz = (float)dzb;
+            o[e] = dzb;
+            s1[e] += dz;
+            s2[e] += dz * (yf * ca[e] + cb[e]);
+          }
+          *reinterpret_cast<bf16x8*>(op) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
+      if (l15 == 15) {
+        const int col = wn * (BN / WN) + 16 * (p + (g & 1)) + 8 * (g >> 1) + e;
+        red[(wm * BN + col) * 2 + 0] = a;
+        red[(wm * BN + col) * 2 + 1] = b;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    const int co = nt * BN + tid;
+    if (co < k.cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WM; ++w_) {
+        a += red[(w_ * BN + tid) * 2 + 0];
+        b += red[(w_ * BN + tid) * 2 + 1];
+      }
+      float* o = k.bn_parts + ((int64_t)mt * k.cout + co) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, bool BNB = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
   using TL = Tile<T>;
   constexpr int VEC = TL::VEC, SEGS = TL::SEGS, ROWB = TL::ROWB;
@@ -316,6 +427,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
 
   // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
+  if constexpr (BNB && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: its own instantiation
+    __syncthreads();        // the partial sums go through LDS that aliases the ring
+    epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    return;
+  }
   T* __restrict__ yp = static_cast<T*>(k.y);
   const int co_w = nt * BN + wn * (BN / WN);
 #pragma unroll
@@ -402,7 +518,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 //     s_barrier per K-step (never a full drain).
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
@@ -591,6 +707,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   __syncthreads();
 
   // ---- epilogue (identical to the register-staged kernel)
+  if constexpr (BNB) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
+    epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    return;
+  }
   T* __restrict__ yp = static_cast<T*>(k.y);
   const int co_w = nt * BN + wn * (BN / WN);
 #pragma unroll
@@ -673,6 +793,12 @@ inline TileSel pick_tile(int cout, int dtype, int64_t M, int ktot = 1 << 30) {
   return {256, 16};
 }
 
+// the fused BatchNorm-backward epilogue exists for bf16 tiles with an even number of co fragments and 16-byte stores
+inline bool bnb_ok(const sfk_conv_desc* d) {
+  return d->x.dtype == SFK_BF16 && d->cout > 16 && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0 &&
+         (((uintptr_t)d->y.ptr) & 15) == 0;
+}
+
 int validate(const sfk_conv_desc* d) {
   if (!d || !d->w) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
@@ -692,6 +818,20 @@ int validate(const sfk_conv_desc* d) {
   if (!sfk_fmap_vec_ok(&d->x)) return SFK_ERR_UNSUPPORTED;
   if ((d->y.c % 4) || (d->y.ld % 4) || (d->y.c_off % 4) || (((uintptr_t)d->y.ptr) & 15)) return SFK_ERR_UNSUPPORTED;
   if (((uintptr_t)d->w) & 15) return SFK_ERR_UNSUPPORTED;
+  if (d->bnb.partials) {
+    const sfk_bn_bwd_fuse& b = d->bnb;
+    if (d->stats || !sfk_fmap_ok(&b.y_bn) || !b.mean || !b.invstd) return SFK_ERR_INVALID;
+    if (b.y_bn.n != d->y.n || b.y_bn.t != d->y.t || b.y_bn.h != d->y.h || b.y_bn.w != d->y.w || b.y_bn.c != d->y.c ||
+        b.y_bn.dtype != d->y.dtype)
+      return SFK_ERR_INVALID;
+    if (b.mask_src.ptr && (!sfk_fmap_ok(&b.mask_src) || b.mask_src.n != d->y.n || b.mask_src.t != d->y.t ||
+                           b.mask_src.h != d->y.h || b.mask_src.w != d->y.w || b.mask_src.c != d->y.c ||
+                           b.mask_src.dtype != d->y.dtype))
+      return SFK_ERR_INVALID;
+    if (!b.mask_src.ptr && b.relu && (!b.scale || !b.shift)) return SFK_ERR_INVALID;
+    if (!bnb_ok(d)) return SFK_ERR_UNSUPPORTED;
+    if (!sfk_fmap_vec_ok(&b.y_bn) || (b.mask_src.ptr && !sfk_fmap_vec_ok(&b.mask_src))) return SFK_ERR_UNSUPPORTED;
+  }
   // buffer resources address 32 bits
   const int64_t esz = d->x.dtype == SFK_BF16 ? 2 : 4;
   if (sfk_fmap_bytes(&d->x) >= (1ll << 32) - 64 || (int64_t)d->cout * d->wtaps * d->cin * esz >= (1ll << 32) - 64)
@@ -700,6 +840,12 @@ int validate(const sfk_conv_desc* d) {
 }
 
 int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
+  if (k.bn_parts) {
+    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, true>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, s, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2>), grid, dim3(512), 0, s, k);
   else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, k);
   SFK_CHECK_LAUNCH();
@@ -722,6 +868,13 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dspt.set(d->cin / vec);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  k.bn_parts = d->bnb.partials;
+  if (k.bn_parts) {
+    k.bn_y = d->bnb.y_bn.ptr; k.bn_yld = d->bnb.y_bn.ld; k.bn_yoff = d->bnb.y_bn.c_off;
+    k.bn_mask = d->bnb.mask_src.ptr; k.bn_mld = d->bnb.mask_src.ld; k.bn_moff = d->bnb.mask_src.c_off;
+    k.bn_relu = d->bnb.relu;
+    k.bn_mean = d->bnb.mean; k.bn_invstd = d->bnb.invstd; k.bn_scale = d->bnb.scale; k.bn_shift = d->bnb.shift;
+  }
   static const int kshort = getenv("SFK_KSHORT") ? atoi(getenv("SFK_KSHORT")) : 5;   // A/B knob
   k.kshort = kshort;
   k.lin_out = d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
@@ -739,6 +892,16 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   if (sizeof(T) == 2 && ts.bn == 128) {
     if (k.xbytes < 0x7FF00000u && k.wbytes < 0x7FF00000u) return launch_dma(k, ts.bm, grid, s);
     return SFK_ERR_UNSUPPORTED;   // the DMA path addresses < 2 GiB per operand
+  }
+  if (k.bn_parts) {          // fused BatchNorm-backward reduce (bf16, cout > 16: tiles of 32..128 output channels)
+    if constexpr (sizeof(T) == 2) {
+      if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, true>), grid, block, 0, s, k);
+      else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, true>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, true>), grid, block, 0, s, k);
+      SFK_CHECK_LAUNCH();
+      return SFK_OK;
+    }
+    return SFK_ERR_UNSUPPORTED;
   }
   if (k.KC <= k.kshort && ts.bn <= 32) {   // (the wider tiles spill with the exact-count loop: 124..228 B per lane)
     if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, true>), grid, block, 0, s, k);
@@ -761,6 +924,14 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
   const int bm = pick_tile(d->cout, d->x.dtype, M, d->ntaps * d->cin).bm;
   return (int)((M + bm - 1) / bm);
+}
+
+extern "C" int sfk_conv_bnb_supported(const sfk_conv_desc* d) {
+  if (!d) return 0;
+  sfk_conv_desc c = *d;
+  c.bnb.partials = nullptr;
+  if (validate(&c) != SFK_OK) return 0;
+  return bnb_ok(d) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream) {

@@ -14,13 +14,14 @@ per-channel statistics, master weights, gradients and the head are fp32.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
 from . import arch
-from ._lib import BN_FOLD_ROWS, ConvPass, FMap, StemSrc, WgradPass, stem_kp
+from ._lib import BN_FOLD_ROWS, BnBwdFuse, ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
@@ -132,6 +133,7 @@ class Engine:
         self._plans: Dict[tuple, Plan] = {}
         self._build_params(seed)
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
+        self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "1") != "0"   # BatchNorm-backward reduce in dgrad epilogues
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -374,17 +376,23 @@ class Engine:
                       bytes=float(y.pixels * y.c * esz * (2 + (1 if res is not None else 0))))
 
     def _bn_bwd(self, pl: Plan, rec: _UnitRec, da: FMap, tag: str, relu: bool, mask_src: Optional[FMap],
-                dz_inplace: bool, dy: FMap):
-        """BatchNorm(+ReLU) backward of one unit: da -> dy (may alias da), accumulates dgamma/dbeta."""
+                dz_inplace: bool, dy: FMap, reduced=None):
+        """BatchNorm(+ReLU) backward of one unit: da -> dy (may alias da), accumulates dgamma/dbeta.
+        reduced = (partials, rows): the pass that produced da already masked it (da holds dz) and left the partial
+        sums (fused epilogue, _dgrad(fuse=...)), so the reduce kernel is skipped."""
         L = rec.L
-        parts = self._buf(f"bparts.{tag}", MAX_PARTS * L.c * 2, torch.float32)
         coef = self._buf(f"coef.{tag}", L.c * 3, torch.float32)
-        run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
-                                         da if dz_inplace else None, parts, MAX_PARTS)
         esz = 2 if self.dtype == torch.bfloat16 else 4
         el = float(rec.y.pixels * L.c * esz)
-        pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
-                      bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0)))
+        if reduced is not None:
+            parts, np_ = reduced
+            dz_inplace = True
+        else:
+            parts = self._buf(f"bparts.{tag}", MAX_PARTS * L.c * 2, torch.float32)
+            run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
+                                             da if dz_inplace else None, parts, MAX_PARTS)
+            pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
+                          bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0)))
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                               self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
                                               self._fold_ws(tag, L.c)))
@@ -415,8 +423,11 @@ class Engine:
                       bytes=float(esz * (rec.x.pixels * L.eg.cin + dy.pixels * L.eg.cout) + 4 * L.w_numel))
         pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
 
-    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool):
-        """data gradient of rec's conv: dy -> dx (+= when accumulate)."""
+    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None):
+        """data gradient of rec's conv: dy -> dx (+= when accumulate).
+        fuse = (bn unit whose activation gradient dx is, mask_src | None, relu, tag): fold that unit's BatchNorm-backward
+        reduce into this pass's epilogue when the backend can (single stride-1 pass, bf16, > 16 channels); returns
+        (partials, rows) then -- dx holds dz and the caller skips the reduce kernel -- else None."""
         L = rec.L
         assert L.needs_dgrad
         passes, needs_zero = dgrad_passes(L.eg, (rec.x.t, rec.x.h, rec.x.w))
@@ -425,14 +436,25 @@ class Engine:
             pl.bwd.append(self.be.fill_zero(dx.buf[: dx.pixels * dx.ld]))
         wt = self.St[L.w_off:L.w_off + L.w_numel]
         esz = 2 if self.dtype == torch.bfloat16 else 4
+        reduced = None
         for sp in passes:
             rows = dy.n * sp.rows[0] * sp.rows[1] * sp.rows[2]
-            pl.bwd.append(self.be.conv_igemm(ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt,
-                                                      L.eg.wtaps, L.eg.cout, L.eg.cin, accumulate=accumulate)),
+            cp = ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, L.eg.wtaps, L.eg.cout, L.eg.cin,
+                          accumulate=accumulate)
+            extra = 0.0
+            if fuse is not None and self.fuse_bn_bwd and len(passes) == 1 and self.be.conv_bnb_supported(cp):
+                brec, mask_src, relu, tag = fuse
+                mt = self.be.conv_igemm_mtiles(cp)
+                parts = self._buf(f"bparts.{tag}", max(mt, 1) * brec.L.c * 2, torch.float32)
+                cp.bnb = BnBwdFuse(brec.y, mask_src, brec.mean, brec.invstd, brec.scale, brec.shift, relu, parts)
+                reduced = (parts, mt)
+                extra = float(esz * rows * L.eg.cin * (2 if mask_src is not None else 1))
+            pl.bwd.append(self.be.conv_igemm(cp),
                           kind="conv_dgrad", layer=L.cb.conv_key, cout=L.eg.cin,
                           flops=2.0 * rows * L.eg.cout * L.eg.cin * len(sp.taps),
                           bytes=float(esz * (dy.pixels * L.eg.cout / len(passes) + rows * L.eg.cin * (2 if accumulate else 1)
-                                             + L.w_numel)))
+                                             + L.w_numel)) + extra)
+        return reduced
 
     # ---- stem: direct (kt,7,7)/(1,2,2) conv from the clip -> BN -> ReLU -> MaxPool
     def _stem_ops(self, pl: Plan, p: int, x5: torch.Tensor, t_index, rec=None):
@@ -540,32 +562,49 @@ class Engine:
             self._apply(pl, yc, sc, hc, x, None, None, True, out)
         return (blk, tag, x, out, rec1, reca, recb, recc)
 
-    def _block_bwd(self, pl, brec, d_out: FMap) -> FMap:
-        """d_out: gradient w.r.t. the block output (clobbered).  returns the gradient w.r.t. the block input."""
+    def _block_bwd(self, pl, brec, d_out: FMap, reduced_c=None, prev=None):
+        """d_out: gradient w.r.t. the block output (clobbered).  returns (gradient w.r.t. the block input, reduced)
+        reduced_c: this block's final-BatchNorm reduce was already done by the pass that finished d_out (d_out holds dz);
+        prev: the record of the block that feeds this one through an identity path -- its final-BatchNorm reduce is
+        folded into this block's last data-gradient pass, whose result IS the gradient of prev's output; `reduced`
+        is then what to hand to prev's _block_bwd."""
         blk, tag, x, out, rec1, reca, recb, recc = brec
         n = x.n
         # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
         dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
-        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc)
+        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c)
         self._wgrad(pl, recc, dyc)
         dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
-        self._dgrad(pl, recc, dyc, dab, accumulate=False)
-        self._bn_bwd(pl, recb, dab, f"{tag}.b", True, None, False, dab)
+        red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
+        self._bn_bwd(pl, recb, dab, f"{tag}.b", True, None, False, dab, reduced=red_b)
         self._wgrad(pl, recb, dab)
         daa = self._fmap(f"da.{tag}.a", n, reca.y.t, reca.y.h, reca.y.w, reca.y.c)
-        self._dgrad(pl, recb, dab, daa, accumulate=False)
-        self._bn_bwd(pl, reca, daa, f"{tag}.a", True, None, False, daa)
+        red_a = self._dgrad(pl, recb, dab, daa, accumulate=False, fuse=(reca, None, True, f"{tag}.a"))
+        self._bn_bwd(pl, reca, daa, f"{tag}.a", True, None, False, daa, reduced=red_a)
         self._wgrad(pl, reca, daa)
         if rec1 is None:
-            # identity shortcut: dX = dz + dgrad_a
-            self._dgrad(pl, reca, daa, d_out, accumulate=True)
-            return d_out
+            # identity shortcut: dX = dz + dgrad_a; dX is the gradient of the previous block's output
+            fuse = None
+            if prev is not None:
+                p_tag, p_out, p_recc = prev[1], prev[3], prev[7]
+                fuse = (p_recc, p_out, True, f"{p_tag}.c")
+            red_prev = self._dgrad(pl, reca, daa, d_out, accumulate=True, fuse=fuse)
+            return d_out, red_prev
         dx = self._fmap(f"dx.{tag}", n, x.t, x.h, x.w, x.c)
         self._dgrad(pl, reca, daa, dx, accumulate=False)
         self._bn_bwd(pl, rec1, d_out, f"{tag}.b1", False, None, False, d_out)   # d_out already holds dz
         self._wgrad(pl, rec1, d_out)
         self._dgrad(pl, rec1, d_out, dx, accumulate=True)
-        return dx
+        return dx, None
+
+    def _stage_bwd(self, pl, brecs, d: FMap) -> FMap:
+        """backward of one pathway's stage, last block first; each block's final data-gradient pass also reduces the
+        previous block's last BatchNorm (identity shortcuts only: the first block of a stage ends in its projection)"""
+        reduced = None
+        for i in range(len(brecs) - 1, -1, -1):
+            prev = brecs[i - 1] if i > 0 else None
+            d, reduced = self._block_bwd(pl, brecs[i], d, reduced_c=reduced, prev=prev)
+        return d
 
     def _build_plan(self, x_slow: torch.Tensor, x_fast: torch.Tensor, slow_t_index, train: bool) -> Plan:
         be, spec, W = self.be, self.spec, self.wiring
@@ -679,15 +718,10 @@ class Engine:
         for si in range(3, -1, -1):
             # slow pathway of this stage: d_xs is the gradient of its last block's output
             B_.cur_lane = 0
-            d = d_xs
-            for brec in reversed(stage_recs[si][0]):
-                d = self._block_bwd(pl, brec, d)
+            d = self._stage_bwd(pl, stage_recs[si][0], d_xs)
             d_cat = d                                   # gradient of the (concatenated) slow input of this stage
             B_.cur_lane = 1
-            d = d_xf
-            for brec in reversed(stage_recs[si][1]):
-                d = self._block_bwd(pl, brec, d)
-            d_xf = d
+            d_xf = self._stage_bwd(pl, stage_recs[si][1], d_xf)
             c_prev = xs_fulls[si].c - (W.fusions[si].geom.cout if fuse else 0)
             if fuse:
                 B_.sync(1, 0)                           # the fusion's gradient comes out of the slow pathway's d_cat
