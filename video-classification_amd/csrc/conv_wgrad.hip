@@ -50,13 +50,24 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 template <typename T, int TC> struct WT;
 template <int TC> struct WT<bf16_t, TC> {
-  static constexpr int VEC = 8, SEGS = TC / 8, ROWB = TC * 2 + 16;
+  // rows of TC channels, no padding; the 32-byte blocks (16 channels = one transposed fragment) of row r are stored at
+  // block index  b ^ swz(r),  chosen so that the 8 rows a ds_read_b64_tr_b16 half-wave touches (r = 8g+q, g in {0,1},
+  // q in 0..3) land on 8 disjoint 32-byte bank windows (the padded layout conflicted 2-way: 35 % of the LDS cycles)
+  static constexpr int VEC = 8, SEGS = TC / 8, ROWB = TC * 2, NB = TC / 16;
   typedef bf16x8 frag;
+  static __device__ __forceinline__ int swz(int r) {
+    if (NB >= 8) return (r & 3) | (((r >> 3) & 1) << 2);
+    if (NB == 4) return ((r >> 1) & 1) | (((r >> 3) & 1) << 1);
+    return NB == 2 ? ((r >> 3) & 1) : 0;
+  }
+  // byte offset of 16-byte segment `seg` of row r
+  static __device__ __forceinline__ int off(int r, int seg) { return r * ROWB + ((((seg >> 1) ^ swz(r)) << 1) | (seg & 1)) * 16; }
   // fragment for channels c0..c0+15: lane (g = lane>>4, q = (lane&15)>>2, p = lane&3) addresses row 8g+q (+4),
   // columns c0+4p..c0+4p+3; the transpose read hands lane i of the group column c0+i of those 4 rows.
   static __device__ __forceinline__ frag load(const char* tile, int c0, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const char* a = tile + (8 * g + q) * ROWB + (c0 + 4 * p) * 2;
+    const int r = 8 * g + q;                       // rows r and r+4 share swz (bit 2 is not part of it)
+    const char* a = tile + r * ROWB + (((c0 >> 4) ^ swz(r)) << 5) + p * 8;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * ROWB));
     frag f;
@@ -72,6 +83,7 @@ struct F32Frag { float v[8]; };
 template <int TC> struct WT<float, TC> {
   static constexpr int VEC = 4, SEGS = TC / 4, ROWB = TC * 4 + 16;
   typedef F32Frag frag;
+  static __device__ __forceinline__ int off(int r, int seg) { return r * ROWB + seg * 16; }
   // MFMA step s takes pixel 4s+g of channel c0 + (lane&15)
   static __device__ __forceinline__ frag load(const char* tile, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
@@ -97,7 +109,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   constexpr int SEGO = WO::SEGS, SEGI = WI::SEGS, ROWO = WO::ROWB, ROWI = WI::ROWB;
   constexpr int R = MK * KS;                       // pixels per stage
   constexpr int FO = TCO / 32, FI = TCI / 32;      // 16-wide fragments per wave (co side, column side)
-  constexpr int NLO = (R * SEGO + 255) / 256, NLI = (R * SEGI + 255) / 256;
+  // A thread OWNS one pixel row of the stage and walks its 16-byte segments (TPR threads per row): the pixel's
+  // (n, t, h, w) decomposition -- three divisions -- is done once per thread and stage instead of once per segment
+  // (the gather arithmetic outweighed the MFMAs 10..17 : 1 in the narrow layers).
+  constexpr int TPR = 256 / R;
+  constexpr int NLO = SEGO / TPR, NLI = SEGI / TPR;
+  static_assert(TPR >= 1 && SEGO % TPR == 0 && SEGI % TPR == 0 && NLO >= 1 && NLI >= 1, "staging shape");
   constexpr int TILEO = R * ROWO, TILEI = R * ROWI, BUF = TILEO + TILEI;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   __shared__ sfk_tap s_taps[SFK_MAX_TAPS + 1];
@@ -119,66 +136,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
 
   const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
   const __amdgpu_buffer_rsrc_t drs = sfk_make_rsrc(k.dy, k.dbytes);
+  const int row = tid / TPR, q = tid % TPR;        // this thread's pixel row of the stage, first segment
 
   // column segment -> (tap, channel) of this thread's X slots (fixed for the whole kernel)
-  int xi_row[NLI], xi_soff[NLI], xi_cb[NLI];
+  int xi_soff[NLI], xi_cb[NLI];
   sfk_tap xi_tap[NLI];
   bool xi_ok[NLI];
 #pragma unroll
   for (int i = 0; i < NLI; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx / SEGI, seg = idx % SEGI;
+    const int seg = q + i * TPR;
     uint32_t tap, cseg;
     k.dspt.divmod((uint32_t)(cit * SEGI + seg), tap, cseg);
-    xi_ok[i] = idx < R * SEGI && tap < (uint32_t)k.ntaps;
-    xi_tap[i] = s_taps[tap < (uint32_t)k.ntaps ? tap : SFK_MAX_TAPS];
-    xi_row[i] = row;
-    xi_soff[i] = row * ROWI + seg * 16;
+    xi_ok[i] = tap < (uint32_t)k.ntaps;
+    xi_tap[i] = s_taps[xi_ok[i] ? tap : SFK_MAX_TAPS];
+    xi_soff[i] = WI::off(row, seg);
     xi_cb[i] = ((int)cseg * VEC + k.xoff) * (int)sizeof(T);
   }
-  // dY slots: (row, channel segment) with the byte offset inside a pixel record
+  // dY slots: channel segments of the same row
   uint32_t di_off[NLO];
+  int di_soff[NLO];
 #pragma unroll
   for (int i = 0; i < NLO; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx / SEGO, seg = idx % SEGO;
+    const int seg = q + i * TPR;
     const int co = cot * TCO + seg * VEC;
-    di_off[i] = (idx < R * SEGO && co < k.cout) ? (uint32_t)((row * k.dld + k.doff + co) * (int)sizeof(T)) : SFK_OOB;
+    di_off[i] = co < k.cout ? (uint32_t)((k.doff + co) * (int)sizeof(T)) : SFK_OOB;
+    di_soff[i] = WO::off(row, seg);
   }
   uint4 dr[NLO], xr[NLI];
   const bool linear = k.ntaps == 1 && k.taps[0].dt == 0 && k.taps[0].dh == 0 && k.taps[0].dw == 0 && k.gst == 1 &&
                       k.gsh == 1 && k.gsw == 1 && k.xt == (int)k.drt.d && k.xh == (int)k.drh.d && k.xw == (int)k.drw.d;
   // branch-free buffer loads: padding taps, rows past M and ragged channels read zeros through SFK_OOB
   auto gload = [&](int stage) {
-    const int m0 = stage * R;
-    const uint32_t rows_left = (uint32_t)(k.M - m0);       // stage <= nchunks-1 => > 0; past the end => huge -> all OOB below
+    const int m = stage * R + row;
+    const bool mok = stage < k.nchunks && m < k.M;       // past the end: every slot OOB (zeros), keeps the body branch-free
+    const uint32_t drow = (uint32_t)m * (uint32_t)(k.dld * (int)sizeof(T));
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) {
-      const int idx = tid + i * 256;
-      const bool ok = di_off[i] != SFK_OOB && m0 < k.M && (uint32_t)(idx / SEGO) < rows_left;
-      dr[i] = sfk_buffer_load16(drs, ok ? (uint32_t)m0 * (uint32_t)(k.dld * (int)sizeof(T)) + di_off[i] : SFK_OOB);
-    }
-    if (linear) {   // pointwise stride-1 conv: the gathered pixel IS the row (wave-uniform branch, no index arithmetic)
+    for (int i = 0; i < NLO; ++i) dr[i] = sfk_buffer_load16(drs, (mok && di_off[i] != SFK_OOB) ? drow + di_off[i] : SFK_OOB);
+    if (linear) {   // pointwise stride-1 conv: the gathered pixel IS the row
+      const uint32_t xrow = (uint32_t)m * (uint32_t)(k.xld * (int)sizeof(T));
 #pragma unroll
-      for (int i = 0; i < NLI; ++i) {
-        const int m = m0 + xi_row[i];
-        const bool ok = xi_ok[i] && m < k.M;
-        xr[i] = sfk_buffer_load16(xrs, ok ? (uint32_t)m * (uint32_t)(k.xld * (int)sizeof(T)) + (uint32_t)xi_cb[i] : SFK_OOB);
-      }
+      for (int i = 0; i < NLI; ++i) xr[i] = sfk_buffer_load16(xrs, (mok && xi_ok[i]) ? xrow + (uint32_t)xi_cb[i] : SFK_OOB);
       return;
     }
+    uint32_t q1, rw_, q2, rh_, n_, rt_;
+    k.drw.divmod((uint32_t)m, q1, rw_);
+    k.drh.divmod(q1, q2, rh_);
+    k.drt.divmod(q2, n_, rt_);
+    const int tb = (int)rt_ * k.gst, hb = (int)rh_ * k.gsh, wb = (int)rw_ * k.gsw;
+    const uint32_t nb = (uint32_t)n_ * k.xt;
 #pragma unroll
     for (int i = 0; i < NLI; ++i) {
-      const int m = m0 + xi_row[i];
-      uint32_t q1, rw_, q2, rh_, n_, rt_;
-      k.drw.divmod((uint32_t)m, q1, rw_);
-      k.drh.divmod(q1, q2, rh_);
-      k.drt.divmod(q2, n_, rt_);
-      const int ti = (int)rt_ * k.gst + xi_tap[i].dt, hi = (int)rh_ * k.gsh + xi_tap[i].dh,
-                wi = (int)rw_ * k.gsw + xi_tap[i].dw;
-      const bool ok = xi_ok[i] && m < k.M && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
+      const int ti = tb + xi_tap[i].dt, hi = hb + xi_tap[i].dh, wi = wb + xi_tap[i].dw;
+      const bool ok = mok && xi_ok[i] && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
                       (unsigned)wi < (unsigned)k.xw;
-      const uint32_t pix = (((uint32_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi;
+      const uint32_t pix = ((nb + ti) * k.xh + hi) * k.xw + wi;
       xr[i] = sfk_buffer_load16(xrs, ok ? pix * (uint32_t)(k.xld * (int)sizeof(T)) + (uint32_t)xi_cb[i] : SFK_OOB);
     }
   };
@@ -186,13 +197,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
     char* ds = smem + buf * BUF;
     char* xs = ds + TILEO;
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < R * SEGO) *reinterpret_cast<uint4*>(ds + (idx / SEGO) * ROWO + (idx % SEGO) * 16) = dr[i];
-    }
+    for (int i = 0; i < NLO; ++i) *reinterpret_cast<uint4*>(ds + di_soff[i]) = dr[i];
 #pragma unroll
-    for (int i = 0; i < NLI; ++i)
-      if (tid + i * 256 < R * SEGI) *reinterpret_cast<uint4*>(xs + xi_soff[i]) = xr[i];
+    for (int i = 0; i < NLI; ++i) *reinterpret_cast<uint4*>(xs + xi_soff[i]) = xr[i];
   };
 
   f32x4 acc[FO][FI];
