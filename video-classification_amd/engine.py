@@ -134,6 +134,7 @@ class Engine:
         self._build_params(seed)
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "1") != "0"   # BatchNorm-backward reduce in dgrad epilogues
+        self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -412,16 +413,25 @@ class Engine:
                        L.eg.cin, L.eg.cout)
         # scratch for the split sums: one buffer per pathway stream (launches on a stream are ordered), grown to the
         # largest request; the descriptor keeps the pointer, so size it before binding
+        # Filter gradients feed nothing downstream in the step (only Adam reads dW), so they leave the pathway's
+        # dependency chain (BN backward -> dgrad -> BN backward ...) for a lane of their own and fill the gaps that chain
+        # leaves on the chip; the lane waits for the producer of dy, everything joins before the optimiser.
+        home = pl.bwd.cur_lane
+        wl = home + 2 if self.wgrad_lanes else home
+        if wl != home:
+            pl.bwd.sync(wl, home)
+            pl.bwd.cur_lane = wl
         need = self.be.conv_wgrad_workspace_bytes(wp)
         if need > 0:
-            cap = self._wg_ws_need.get(pl.bwd.cur_lane, 0)
-            self._wg_ws_need[pl.bwd.cur_lane] = max(cap, need)
-            self._wg_pending.append((pl.bwd, len(pl.bwd), wp, pl.bwd.cur_lane))
+            cap = self._wg_ws_need.get(wl, 0)
+            self._wg_ws_need[wl] = max(cap, need)
+            self._wg_pending.append((pl.bwd, len(pl.bwd), wp, wl))
         pl.bwd.append(self.be.conv_wgrad(wp),
                       kind="conv_wgrad", layer=L.cb.conv_key, cout=L.eg.cout,
                       flops=2.0 * dy.pixels * L.eg.cout * L.eg.cin * L.eg.wtaps,
                       bytes=float(esz * (rec.x.pixels * L.eg.cin + dy.pixels * L.eg.cout) + 4 * L.w_numel))
         pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
+        pl.bwd.cur_lane = home
 
     def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None):
         """data gradient of rec's conv: dy -> dx (+= when accumulate).
@@ -732,6 +742,9 @@ class Engine:
         B_.cur_lane = 1
         self._stem_bwd(pl, 1, stem_recs[1], d_xf)
         B_.sync(0, 1)                                   # join before the optimiser
+        if self.wgrad_lanes:
+            B_.sync(0, 2)
+            B_.sync(0, 3)
         B_.cur_lane = 0
         # bind the filter-gradient ops to their lane's scratch now that its size is known
         for oplist, slot, wp, lane in self._wg_pending:
@@ -778,27 +791,28 @@ class Engine:
         for op in ops:
             op(stream)
 
+    NLANES = 4     # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway
+
     def lane_streams(self):
-        """torch streams the two pathway lanes run on (one entry when the schedule is single-stream / on the CPU)"""
+        """torch streams the schedule's lanes run on (one entry when the schedule is single-stream / on the CPU)"""
         if self.device.type != "cuda":
             return []
         main = torch.cuda.current_stream(self.device)
         if not self.two_streams:
             return [main]
         if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
-        return [main, self._side]
+            self._side = [torch.cuda.Stream(self.device) for _ in range(self.NLANES - 1)]
+        return [main] + self._side
 
     def _run_lanes(self, ops: "OpList", begin: int = 0, end: Optional[int] = None):
-        """Run ops[begin:end] of a schedule on two streams: pathway 0 on the current stream, pathway 1 on a side
-        stream, ordered by the Wait markers (events).  Capturable: the side stream forks from / joins into the
-        capturing stream."""
+        """Run ops[begin:end] of a schedule on its lanes: lane 0 on the current stream, the others on side streams,
+        ordered by the Wait markers (events).  Capturable: the side streams fork from / join into the capturing
+        stream."""
         end = len(ops) if end is None else end
         if self.device.type != "cuda" or not self.two_streams:
             return self._run(ops[begin:end], self._stream())
         streams = self.lane_streams()
-        main = streams[0]
-        handles = (main.cuda_stream, self._side.cuda_stream)
+        handles = [s.cuda_stream for s in streams]
         for i in range(begin, end):
             op, lane = ops[i], ops.lane[i]
             if isinstance(op, Wait):
