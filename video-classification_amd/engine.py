@@ -135,6 +135,9 @@ class Engine:
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "1") != "0"   # BatchNorm-backward reduce in dgrad epilogues
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
+        # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
+        # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
+        self.deterministic_wgrad = os.environ.get("SFK_WGWS", "0") == "1"
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -411,7 +414,7 @@ class Engine:
         esz = 2 if self.dtype == torch.bfloat16 else 4
         wp = WgradPass(rec.x, dy, L.eg.s, list(wgrad_taps(L.eg)), self._gslice(L.w_off, L.w_numel), L.eg.wtaps,
                        L.eg.cin, L.eg.cout)
-        # scratch for the split sums: one buffer per pathway stream (launches on a stream are ordered), grown to the
+        # optional scratch for the split sums (deterministic_wgrad): one buffer per lane (launches on a stream are ordered), grown to the
         # largest request; the descriptor keeps the pointer, so size it before binding
         # Filter gradients feed nothing downstream in the step (only Adam reads dW), so they leave the pathway's
         # dependency chain (BN backward -> dgrad -> BN backward ...) for a lane of their own and fill the gaps that chain
@@ -421,7 +424,7 @@ class Engine:
         if wl != home:
             pl.bwd.sync(wl, home)
             pl.bwd.cur_lane = wl
-        need = self.be.conv_wgrad_workspace_bytes(wp)
+        need = self.be.conv_wgrad_workspace_bytes(wp) if self.deterministic_wgrad else 0
         if need > 0:
             cap = self._wg_ws_need.get(wl, 0)
             self._wg_ws_need[wl] = max(cap, need)
