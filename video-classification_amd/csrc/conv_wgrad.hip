@@ -520,7 +520,9 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   const int base = cotiles * k.citiles;
   // pixel splits: one resident generation of workgroups (2 x 256 CUs for the 8-wave tile, 3 x 256 for the 4-wave one).
   // Every split adds a full copy of the tile to the fp32 atomic traffic (~1.3 TB/s chip-wide), so do not over-split.
-  int splits = ((NW == 8 ? 512 : 768) + base - 1) / base;
+  static const int target8 = getenv("SFK_WGT8") ? atoi(getenv("SFK_WGT8")) : 384;   // A/B knobs: resident-block targets
+  static const int target4 = getenv("SFK_WGT4") ? atoi(getenv("SFK_WGT4")) : 512;
+  int splits = ((NW == 8 ? target8 : target4) + base - 1) / base;
   const int max_splits = (k.nchunks + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

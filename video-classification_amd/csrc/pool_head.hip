@@ -11,9 +11,12 @@ struct FM {
 inline FM fm_of(const sfk_fmap* f) { return FM{f->ptr, f->t, f->h, f->w, f->ld, f->c_off}; }
 
 // ------------------------------------------------------------------ MaxPool (1,k,k)/(1,s,s)/(0,p,p)
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* argmax, int n, int c, int k, int s,
-                                                          int p, FastDiv dcg, FastDiv dwo, FastDiv dho) {
+// KC/SC/PC > 0: window / stride / padding known at compile time (the stems' (3, 2, 1)): the window loops unroll and the
+// backward's divisibility tests fold to parity tests
+template <typename T, int KC = 0, int SC = 0, int PC = 0>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* argmax, int n, int c, int k_, int s_,
+                                                          int p_, FastDiv dcg, FastDiv dwo, FastDiv dho) {
+  const int k = KC ? KC : k_, s = KC ? SC : s_, p = KC ? PC : p_;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const int64_t total = (int64_t)n * y.t * y.h * y.w * cgs;
@@ -61,9 +64,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(FM dy, const uint8_t* argmax, FM dx, int n, int c, int k,
-                                                          int s, int p, FastDiv dcg, FastDiv dwi, FastDiv dhi) {
+template <typename T, int KC = 0, int SC = 0, int PC = 0>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(FM dy, const uint8_t* argmax, FM dx, int n, int c, int k_,
+                                                          int s_, int p_, FastDiv dcg, FastDiv dwi, FastDiv dhi) {
+  const int k = KC ? KC : k_, s = KC ? SC : s_, p = KC ? PC : p_;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const int64_t total = (int64_t)n * dx.t * dx.h * dx.w * cgs;
@@ -370,9 +374,12 @@ extern "C" int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* ar
   dcg.set(cgs); dwo.set(y->w); dho.set(y->h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (x->dtype == SFK_BF16)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
+    if (k == 3 && s == 2 && p == 1)
+      hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 3, 2, 1>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
+    else
+      hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -390,9 +397,12 @@ extern "C" int sfk_maxpool_bwd(const sfk_fmap* dy, const uint8_t* argmax, const 
   dcg.set(cgs); dwi.set(dx->w); dhi.set(dx->h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dx->dtype == SFK_BF16)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, fm_of(dy), argmax, fm_of(dx), dx->n, dx->c, k, s, p, dcg, dwi, dhi);
+    if (k == 3 && s == 2 && p == 1)
+      hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 3, 2, 1>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(dy), argmax, fm_of(dx), dx->n, dx->c, k, s, p, dcg, dwi, dhi);
+    else
+      hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(dy), argmax, fm_of(dx), dx->n, dx->c, k, s, p, dcg, dwi, dhi);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, fm_of(dy), argmax, fm_of(dx), dx->n, dx->c, k, s, p, dcg, dwi, dhi);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(dy), argmax, fm_of(dx), dx->n, dx->c, k, s, p, dcg, dwi, dhi);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
