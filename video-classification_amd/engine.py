@@ -133,7 +133,9 @@ class Engine:
         self._plans: Dict[tuple, Plan] = {}
         self._build_params(seed)
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
-        self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "1") != "0"   # BatchNorm-backward reduce in dgrad epilogues
+        # BatchNorm-backward reduce folded into the dgrad epilogues (sfk_conv_desc.bnb): removes 3.3 ms of reduce kernels,
+        # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
+        self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
         # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
         # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
