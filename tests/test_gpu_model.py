@@ -197,3 +197,41 @@ def test_benchmark_geometry_properties_bf16():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0] * 0.7, losses
     assert abs(losses[0] - np.log(400)) < 1.0, losses               # random init: close to ln(400)
+
+
+@pytest.mark.parametrize("variant", ["fused_bn_bwd", "deterministic_wgrad", "one_stream"])
+def test_schedule_variants_agree_bf16(variant):
+    """The opt-in engine variants compute the SAME training step as the default schedule (bf16, canonical 8x8 model): the BatchNorm-backward reduce fused into the dgrad epilogues, the atomics-free filter-gradient
+    workspace (bit-reproducible between two runs), and everything on one stream instead of four lanes.  Metric clip size,
+    batch 2."""
+    from video_classification_amd.train import TrainStep
+    gen = torch.Generator().manual_seed(77)
+    frames = torch.randn(2, 3, 32, 224, 224, generator=gen).to(torch.bfloat16).to(DEV)   # the head pools need 7x7 maps
+    labels = torch.tensor([3, 250], device=DEV)
+    idx = pack_pathway_index(32, 4, DEV)
+
+    def run(**attrs):
+        m = SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, backend=hip_backend(), seed=5)
+        for k, v in attrs.items():
+            setattr(m.engine, k, v)
+        step = TrainStep(m.engine, lr=0.0, use_graph=False)            # lr 0: the arena G is the result
+        loss = float(step(frames, frames, labels, slow_t_index=idx))
+        torch.cuda.synchronize()
+        return loss, m.engine.G.clone()
+
+    base_loss, base_g = run(fuse_bn_bwd=False, deterministic_wgrad=False, two_streams=True)
+    if variant == "fused_bn_bwd":
+        loss, g = run(fuse_bn_bwd=True)
+    elif variant == "deterministic_wgrad":
+        loss, g = run(deterministic_wgrad=True)
+        loss2, g2 = run(deterministic_wgrad=True)
+        conv = slice(0, SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, backend=hip_backend()).engine.conv_total)
+        # the stems still flush with atomics; every other conv's filter gradient repeats bit for bit
+        assert float((g[conv] != g2[conv]).float().mean()) < 0.02
+    else:
+        loss, g = run(two_streams=False)
+    # the forward is the same schedule in every variant.  Warm runs repeat bit for bit; the FIRST step of a fresh process
+    # has shown a loss 2e-5 off in 3 of ~90 cold runs (tools/probe/coldrun3.py; not reproduced since, open item in
+    # DESIGN.md), so the comparison allows that much
+    assert abs(loss - base_loss) < 5e-4 * abs(base_loss)
+    assert rel_l2(g.cpu(), base_g.cpu()) < 2e-3                        # fp32 sums in another order

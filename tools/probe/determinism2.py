@@ -1,0 +1,21 @@
+import sys, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from video_classification_amd import arch
+from video_classification_amd.slowfast import SlowFast, pack_pathway_index
+from video_classification_amd.train import TrainStep
+DEV='cuda'
+gen = torch.Generator().manual_seed(77)
+frames = torch.randn(2, 3, 32, 224, 224, generator=gen).to(torch.bfloat16).to(DEV)
+labels = torch.tensor([3, 250], device=DEV)
+idx = pack_pathway_index(32, 4, DEV)
+def run(**attrs):
+    m = SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, seed=5)
+    for k, v in attrs.items(): setattr(m.engine, k, v)
+    step = TrainStep(m.engine, lr=0.0, use_graph=False)
+    loss = float(step(frames, frames, labels, slow_t_index=idx))
+    torch.cuda.synchronize()
+    pl = m.engine._plan_for(frames, frames, idx, True)
+    return loss, pl.logits.clone(), m.engine.G.clone()
+r = [run() for _ in range(3)] + [run(fuse_bn_bwd=True), run(two_streams=False), run(wgrad_lanes=False)]
+for i, (l, lg, g) in enumerate(r):
+    print(i, repr(l), float((lg - r[0][1]).abs().max()), float((g - r[0][2]).norm() / r[0][2].norm()))
