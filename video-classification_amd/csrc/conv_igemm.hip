@@ -679,12 +679,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
 #pragma unroll
       for (int j = 0; j < FM; ++j) TL::mma(acc[i][j], a[i], b[j]);
   };
+  // lgkmcnt(0) belongs to the wait: the barrier releases the OTHER waves to DMA into the slot this step just read, and
+  // a ds_read that was issued but has not executed yet would then return the new bytes (seen as a rare, timing-dependent
+  // slab of wrong outputs: the compiler sinks the last fragment reads' lgkmcnt wait below the barrier otherwise)
   auto ring_wait = [&]() {
     static_assert(XI + WI >= 2 && XI + WI <= 5, "DMA count");
-    if constexpr (XI + WI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (XI + WI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (XI + WI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
 

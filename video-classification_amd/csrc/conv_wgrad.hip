@@ -406,11 +406,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
+  // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
+  // (see conv_igemm.hip ring_wait)
   auto ring_wait = [&]() {
     static_assert(NDO + NDI >= 2 && NDO + NDI <= 4, "DMA count");
-    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
 
