@@ -109,7 +109,8 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
   a = __uint_as_float(r[0]);
   b = __uint_as_float(r[1]);
 }
-__device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, f32x4 a, f32x4 b, int g, bool acc) {
+__device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, f32x4 a, f32x4 b, int g, bool acc,
+                                            const bf16x8& old) {
   float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
   for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
@@ -117,7 +118,6 @@ __device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, 
   if (co >= cout) return;
   bf16_t* p = pix + co;
   if (acc) {
-    const bf16x8 old = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
   }
@@ -126,7 +126,18 @@ __device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, 
   for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
   *reinterpret_cast<bf16x8*>(p) = o;
 }
-__device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool) {}   // f32 stores are 16 B already
+// the 8 channels a lane will own after the swap, as they are in memory now (accumulate mode).  ALL of a tile's old values
+// are fetched before the first store: interleaved, every load waited out a full round trip behind the previous store
+// (the compiler cannot prove they do not alias), 8 serial trips per lane -- accumulate-mode data gradients ran at 1.9 TB/s
+__device__ __forceinline__ bf16x8 load8_old(const bf16_t* pix, int co_base, int cout, int g) {
+  const int co = co_base + 16 * (g & 1) + 8 * (g >> 1);
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+  return co < cout ? *reinterpret_cast<const bf16x8*>(pix + co) : z;
+}
+__device__ __forceinline__ bf16x8 load8_old(const float*, int, int, int) { return bf16x8{}; }
+__device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool, const bf16x8&) {}   // f32 stores are 16 B already
 
 // 16-lane row sum with DPP shifts (4 VALU ops; __shfl_xor goes through ds_bpermute): the total ends in lane 15 of the row
 __device__ __forceinline__ float row16_sum(float v) {
@@ -434,25 +445,42 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
   T* __restrict__ yp = static_cast<T*>(k.y);
   const int co_w = nt * BN + wn * (BN / WN);
+  const bool wide = sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store;
+  int64_t poffs[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
+      poffs[j] = (int64_t)m * k.yld + k.yoff;
+    } else {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+    }
+  }
+  bf16x8 oldv[FM][(FN + 1) / 2];
+  if (wide && k.accumulate) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+      if (m < k.M) {
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
     if (m < k.M) {
-      int64_t poff;
-      if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
-        poff = (int64_t)m * k.yld + k.yoff;
-      } else {
-        uint32_t q1, rw_, q2, rh_, n_, rt_;
-        k.drw.divmod((uint32_t)m, q1, rw_);
-        k.drh.divmod(q1, q2, rh_);
-        k.drt.divmod(q2, n_, rt_);
-        const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-        poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
-      }
-      if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
+      const int64_t poff = poffs[j];
+      if (wide) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0);
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2]);
       } else {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -716,25 +744,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   }
   T* __restrict__ yp = static_cast<T*>(k.y);
   const int co_w = nt * BN + wn * (BN / WN);
+  const bool wide = sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store;
+  int64_t poffs[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
+      poffs[j] = (int64_t)m * k.yld + k.yoff;
+    } else {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+    }
+  }
+  bf16x8 oldv[FM][(FN + 1) / 2];
+  if (wide && k.accumulate) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+      if (m < k.M) {
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
     if (m < k.M) {
-      int64_t poff;
-      if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
-        poff = (int64_t)m * k.yld + k.yoff;
-      } else {
-        uint32_t q1, rw_, q2, rh_, n_, rt_;
-        k.drw.divmod((uint32_t)m, q1, rw_);
-        k.drh.divmod(q1, q2, rh_);
-        k.drt.divmod(q2, n_, rt_);
-        const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-        poff = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
-      }
-      if (sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store) {
+      const int64_t poff = poffs[j];
+      if (wide) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0);
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2]);
       } else {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
