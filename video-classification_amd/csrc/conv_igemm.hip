@@ -37,6 +37,7 @@ struct ConvK {
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_parts;         // [mtiles][cout][2] = (sum dz, sum dz * x_hat) per row tile; NULL = fusion off
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
+  FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   sfk_tap taps[SFK_MAX_TAPS];
 };
@@ -626,9 +627,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   const int kct = k.cin >> 5;                       // K-steps per tap (uniform mode)
   constexpr uint32_t FAR = 0x80000000u;             // stays out of range after adding any soffset (extents < 2 GiB)
   uint32_t xv[XI], wv[WI];                          // current voffsets (uniform mode)
-  int u_tap = 0, u_kc = 0, p_step = 0;
+  // the K position is a FUNCTION of the step number passed in (wave-uniform, SGPRs): as mutable state captured by the
+  // lambda it lived in scratch memory, and every tap entry drained vmcnt(0) behind a scratch load
 
-  auto issue = [&](int buf, const uint32_t (&xo)[XI], const uint32_t (&wo)[WI], int soff) {
+  auto issue = [&](int buf, const uint32_t (&xo)[XI], const uint32_t (&wo)[WI], int soff) __attribute__((always_inline)) {
     char* xs = smem + buf * BUF + wave * (BM / NW) * ROWB;
     char* ws = smem + buf * BUF + BM * ROWB + wave * (WROWS / NW) * ROWB;
 #pragma unroll
@@ -638,8 +640,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
     for (int j = 0; j < WI; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(ws + 16 * j * ROWB), 16, (int)wo[j], soff, 0, 0);
   };
-  auto dma = [&](int buf) {
+  auto dma = [&](int buf, int step) __attribute__((always_inline)) {
     if (uniform) {
+      const int u_tap = __builtin_amdgcn_readfirstlane((int)k.dkct.div((uint32_t)step));
+      const int u_kc = step - u_tap * kct;
       if (u_kc == 0) {                               // entering tap u_tap (wave-uniform branch)
         if (u_tap < k.ntaps) {
           const sfk_tap tp = s_taps[u_tap];
@@ -661,8 +665,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
         }
       }
       issue(buf, xv, wv, u_kc * 64);
-      if (++u_kc == kct) { u_kc = 0; ++u_tap; }
     } else {
+      const int p_step = step;
       uint32_t xo[XI], wo[WI];
       uint32_t tap, cseg;
       k.dspt.divmod((uint32_t)(p_step * SEGS + seg), tap, cseg);
@@ -680,7 +684,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
 #pragma unroll
       for (int j = 0; j < WI; ++j) wo[j] = (cok && wbase[j] != SFK_OOB) ? wbase[j] + wd : FAR;
       issue(buf, xo, wo, 0);
-      ++p_step;
     }
   };
 
@@ -723,15 +726,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   // slot c: c has landed for every wave (barrier); the DMAs of the next step are in flight.  Issue the step after
   // next into the slot the previous step vacated, run this step, wait until only this wave's newest XI+WI DMAs are
   // outstanding, meet the other waves.
-  dma(0);
-  dma(1);
+  dma(0, 0);
+  dma(1, 1);
   ring_wait();
   for (int it = 0;;) {
-    dma(2); compute(0 * BUF); ring_wait();
+    dma(2, it + 2); compute(0 * BUF); ring_wait();
     if (++it >= k.KC) break;
-    dma(0); compute(1 * BUF); ring_wait();
+    dma(0, it + 2); compute(1 * BUF); ring_wait();
     if (++it >= k.KC) break;
-    dma(1); compute(2 * BUF); ring_wait();
+    dma(1, it + 2); compute(2 * BUF); ring_wait();
     if (++it >= k.KC) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-out-of-range) look-ahead DMAs before LDS is reused
@@ -914,6 +917,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.cin = d->cin; k.cout = d->cout; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
   const int vec = sfk_vec_of(d->x.dtype), segs = BK / vec;
   k.dspt.set(d->cin / vec);
+  k.dkct.set(d->cin / 32 > 0 ? d->cin / 32 : 1);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
   k.bn_parts = d->bnb.partials;
