@@ -331,32 +331,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
 #pragma unroll
   for (int j = 0; j < NDI; ++j) x_lin[j] = x_ok[j] ? (uint32_t)(x_row[j] * k.xld * 2 + x_cb[j]) : FAR;
 
-  auto dma = [&](int stage, int buf) {
+  // The DMA instructions themselves sit in straight-line code (offsets are chosen by selects above them): with the
+  // loads inside the linear / gathered branches the compiler lost track of which ring slot each one writes at the
+  // control-flow merge and drained vmcnt(0) before every stage's fragment reads -- no DMA ever overlapped the MFMAs.
+  auto dma = [&](int stage, int buf) __attribute__((always_inline)) {
     char* ds = smem + buf * BUF;
     char* xs = ds + TILEO;
     const int m0 = stage * R;
     const bool full = m0 + R <= k.M;                  // wave-uniform; the ragged last stage masks rows per lane
     const bool live = stage < stage1;                 // look-ahead past the block's range gathers nothing
+    uint32_t dvo[NDO], xvo[NDI];
+    const int dso = live ? m0 * k.dld * 2 : 0;
+    const int xso = (live && linear) ? m0 * k.xld * 2 : 0;
 #pragma unroll
-    for (int j = 0; j < NDO; ++j) {
-      uint32_t vo = d_off[j];
-      int so = m0 * k.dld * 2;
-      if (!live || (!full && m0 + d_row[j] >= k.M)) vo = FAR;
-      if (!live) so = 0;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(ds + (wave * NDO + j) * 1024), 16, (int)vo, so, 0, 0);
-    }
-    if (linear) {
+    for (int j = 0; j < NDO; ++j) dvo[j] = (!live || (!full && m0 + d_row[j] >= k.M)) ? FAR : d_off[j];
 #pragma unroll
-      for (int j = 0; j < NDI; ++j) {
-        uint32_t vo = x_lin[j];
-        int so = m0 * k.xld * 2;
-        if (!live || (!full && m0 + x_row[j] >= k.M)) vo = FAR;
-        if (!live) so = 0;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16, (int)vo, so, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NDI; ++j) {
+    for (int j = 0; j < NDI; ++j) {
+      uint32_t lin = (!live || (!full && m0 + x_row[j] >= k.M)) ? FAR : x_lin[j];
+      uint32_t gat = FAR;
+      if (!linear) {
         const int m = m0 + x_row[j];
         uint32_t q1, rw_, q2, rh_, n_, rt_;
         k.drw.divmod((uint32_t)m, q1, rw_);
@@ -366,10 +359,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
         const bool ok = live && x_ok[j] && m < k.M && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh &&
                         (unsigned)wi < (unsigned)k.xw;
         const uint32_t pix = (((uint32_t)n_ * k.xt + ti) * k.xh + hi) * k.xw + wi;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16,
-                                                 (int)(ok ? pix * (uint32_t)(k.xld * 2) + (uint32_t)x_cb[j] : FAR), 0, 0, 0);
+        gat = ok ? pix * (uint32_t)(k.xld * 2) + (uint32_t)x_cb[j] : FAR;
       }
+      xvo[j] = linear ? lin : gat;
     }
+#pragma unroll
+    for (int j = 0; j < NDO; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(ds + (wave * NDO + j) * 1024), 16, (int)dvo[j], dso, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NDI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16, (int)xvo[j], xso, 0, 0);
   };
 
   f32x4 acc[4][4];
@@ -387,20 +386,34 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
     a_off[i] = frow * LO + (((wco * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
     b_off[i] = TILEO + frow * LI + (((wci * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
   }
-  auto rd = [&](int off, int rowb) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(smem + off + 4 * rowb));
+  // The transposed reads go through inline asm: beside in-flight LDS-DMA, hipcc (ROCm 7.2) orders every
+  // ds_read_tr intrinsic behind `s_waitcnt vmcnt(0)` -- it cannot tell which ring slot the read touches -- which drained
+  // the look-ahead DMA before every stage (no overlap at all; the .s showed it).  As asm the reads are invisible to that
+  // pass, so their completion is waited for by hand (lgkmcnt(0) before the MFMAs; the ring wait orders them against
+  // the DMA that will overwrite the slot).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  auto rd = [&](int off, int rowb) __attribute__((always_inline)) {
+    bf16x4 lo, hi;
+    const uint32_t a0 = lds0 + (uint32_t)off, a1 = a0 + (uint32_t)(4 * rowb);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
   };
-  auto compute = [&](int slot_base) {
+  auto compute = [&](int slot_base) __attribute__((always_inline)) {
     bf16x8 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = rd(slot_base + a_off[i], LO);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = rd(slot_base + b_off[j], LI);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the MFMAs must not be scheduled above the wait: the asm results are only valid after it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(b[j]));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
