@@ -38,6 +38,7 @@ struct StemK {
   float* stats;
   float* dw;
   int tiles_per_block, ntiles;
+  uint32_t src_bytes, y_bytes;   // extents for the buffer resources of the v2 kernels (fit 32 bits, checked at launch)
 };
 
 template <typename S> __device__ __forceinline__ float ldsrc(const void* p, int64_t off);
@@ -448,18 +449,29 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v2_kernel(const StemK k, int 
   uint4 xr[NXC];
   int n = 0, ho0 = 0, wo0 = 0;
   // frames F0, F0+1 (logical, may lie outside the clip = temporal zero padding)
+  // branch-free: a chunk outside the clip gets an out-of-range offset and the buffer load returns zeros.  With a branch
+  // around every load (`if (inside) x = load`) hipcc waited vmcnt(0) after each one: three serial round trips per pair
+  // in front of the MFMAs instead of one batch behind them.
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
   auto fetch = [&](int F0) {
+    // the two frames of this load, resolved through the frame index ONCE and up front (wave-uniform): a lookup inside
+    // the chunk loop is an ordinary load whose wait drains the chunk loads issued before it
+    int fr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int F = F0 + u;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fr[u] = (f >= 0 && f < k.t_in) ? f : -1;
+    }
 #pragma unroll
     for (int i = 0; i < NXC; ++i) {
-      xr[i] = make_uint4(0, 0, 0, 0);
-      if (x_fr[i] < 0) continue;
-      const int F = F0 + x_fr[i];
-      if (F < 0 || F >= k.t_log) continue;
-      const int frame = k.t_index ? k.t_index[F] : F;
+      const int frame = x_fr[i] == 0 ? fr[0] : fr[1];
+      const bool fok = x_fr[i] >= 0 && frame >= 0;
       const int hi = 2 * ho0 - 3 + x_r[i], wi = 2 * wo0 - 8 + 8 * (x_j[i] & 255), ci = x_j[i] >> 8;
-      if (frame >= 0 && frame < k.t_in && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in)
-        xr[i] = *reinterpret_cast<const uint4*>(src + (int64_t)n * k.sn + (int64_t)ci * k.sc + (int64_t)frame * k.st +
-                                                (int64_t)hi * k.sh + wi);
+      const bool ok = fok && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      const int64_t off = (int64_t)n * k.sn + (int64_t)ci * k.sc + (int64_t)frame * k.st + (int64_t)hi * k.sh + wi;
+      xr[i] = sfk_buffer_load16(srs, ok ? (uint32_t)(off * 2) : SFK_OOB);
     }
   };
   auto stage = [&](int F0) {
@@ -605,27 +617,30 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_v2_kernel(const StemK k) {
     if (e >= CIN * V2_PR * V2_CH) x_ci[i] = -1;
   }
   uint4 xr[NXC], dr[NDC];
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
+  const __amdgpu_buffer_rsrc_t yrs = sfk_make_rsrc(k.y, k.y_bytes);
   auto fetch = [&](int item) {
     int n, tf, ho0, wo0;
     tile_coords(k, item, n, tf, ho0, wo0);
     int frame = k.t_index ? k.t_index[tf] : tf;
     const bool fok = frame >= 0 && frame < k.t_in;
+    if (!fok) frame = 0;
+    // branch-free buffer loads (out-of-range offset -> zeros): all of an item's loads are issued in one batch
 #pragma unroll
     for (int i = 0; i < NXC; ++i) {
       const int hi = 2 * ho0 - 3 + x_r[i], wi = 2 * wo0 - 8 + 8 * x_j[i];
-      xr[i] = make_uint4(0, 0, 0, 0);
-      if (fok && x_ci[i] >= 0 && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in)
-        xr[i] = *reinterpret_cast<const uint4*>(src + (int64_t)n * k.sn + (int64_t)x_ci[i] * k.sc +
-                                                (int64_t)frame * k.st + (int64_t)hi * k.sh + wi);
+      const bool ok = fok && x_ci[i] >= 0 && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      const int64_t off = (int64_t)n * k.sn + (int64_t)(x_ci[i] < 0 ? 0 : x_ci[i]) * k.sc + (int64_t)frame * k.st + (int64_t)hi * k.sh + wi;
+      xr[i] = sfk_buffer_load16(srs, ok ? (uint32_t)(off * 2) : SFK_OOB);
     }
     const int ho = ho0 + (tid >> 4), wo = wo0 + (tid & 15);
     const bool pok = ho < k.ho && wo < k.wo;
 #pragma unroll
     for (int f = 0; f < NDC; ++f) {
       const int to = tf + k.pt - f;
-      dr[f] = make_uint4(0, 0, 0, 0);
-      if (f < k.kt && pok && to >= 0 && to < k.t_out)
-        dr[f] = *reinterpret_cast<const uint4*>(dyp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff);
+      const bool ok = f < k.kt && pok && to >= 0 && to < k.t_out;
+      const int64_t off = ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff;
+      dr[f] = sfk_buffer_load16(yrs, ok ? (uint32_t)(off * 2) : SFK_OOB);
     }
   };
   auto stage = [&]() {
@@ -709,6 +724,14 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_v2_kernel(const StemK k) {
   }
 }
 
+// bytes from s->src to one past the last element any (n, ci, t, h, w) index reaches (positive strides)
+inline int64_t stem_src_extent(const sfk_stem_src* s, int n) {
+  const int64_t esz = s->src_dtype == SFK_BF16 ? 2 : 4;
+  if (s->sn < 0 || s->sc < 0 || s->st < 0 || s->sh < 0 || s->sw < 0) return (int64_t)1 << 40;
+  return esz * ((int64_t)(n - 1) * s->sn + (int64_t)(s->cin - 1) * s->sc + (int64_t)(s->t_in - 1) * s->st +
+                (int64_t)(s->h_in - 1) * s->sh + (int64_t)(s->w_in - 1) * s->sw + 1);
+}
+
 int fill(const sfk_stem_src* s, int cout, int t_out, int ho, int wo, StemK& k) {
   if (!s || !s->src || s->cin <= 0 || s->kt <= 0 || !(s->kt & 1) || s->t_in <= 0 || s->h_in <= 0 || s->w_in <= 0)
     return SFK_ERR_INVALID;
@@ -749,7 +772,10 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
   k.ntiles = y->n * y->t * k.tiles_h * k.tiles_w;
   // canonical fast stem geometry in bf16 with 16-byte addressable rows: temporal pairs over a rolling frame ring
   if (y->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && (s->kt == 5 || s->kt == 3) && y->c <= 8 &&
-      s->sw == 1 && (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15)) {
+      s->sw == 1 && (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15) &&
+      stem_src_extent(s, y->n) < (1ll << 32) - 64) {
+    k.src_bytes = (uint32_t)stem_src_extent(s, y->n);
+    k.y_bytes = 0;
     hipStream_t hs2 = static_cast<hipStream_t>(stream);
     const int nf = s->kt + 1;
     const int lds2 = nf * 3 * F2_PLANE + nf * 6 * 1024 + 8 * 16 * 2 * 4;
@@ -809,7 +835,10 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
   hipStream_t hs = static_cast<hipStream_t>(stream);
   // canonical fast stem geometry in bf16 with 16-byte addressable rows: the input-frame-stationary kernel
   if (dy->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && s->kt <= 5 && dy->c <= 8 && s->sw == 1 &&
-      (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15)) {
+      (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15) &&
+      stem_src_extent(s, dy->n) < (1ll << 32) - 64 && sfk_fmap_bytes(dy) < (1ll << 32) - 64) {
+    k.src_bytes = (uint32_t)stem_src_extent(s, dy->n);
+    k.y_bytes = (uint32_t)sfk_fmap_bytes(dy);
     int blocks = 256 * 3;                       // 3 resident workgroups per CU (LDS 44 KB each)
     if (blocks > k.ntiles) blocks = k.ntiles;
     k.tiles_per_block = (k.ntiles + blocks - 1) / blocks;
