@@ -30,6 +30,33 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; arg[i] = 0; }
     bool first = true;
+    if (KC) {
+      // compile-time window: every tap is loaded (coordinates clamped into the frame, so no branch sits around a load and
+      // all k*k loads are in flight together) and taps outside the frame are skipped afterwards
+      Vec16<T> v[(KC ? KC : 1) * (KC ? KC : 1)];
+#pragma unroll
+      for (int kh = 0; kh < (KC ? KC : 1); ++kh)
+#pragma unroll
+        for (int kw = 0; kw < (KC ? KC : 1); ++kw) {
+          int hi = (int)ho * s - p + kh, wi = (int)wo * s - p + kw;
+          hi = hi < 0 ? 0 : (hi >= x.h ? x.h - 1 : hi);
+          wi = wi < 0 ? 0 : (wi >= x.w ? x.w - 1 : wi);
+          v[kh * (KC ? KC : 1) + kw].load(static_cast<const T*>(x.p) + (((int64_t)nt * x.h + hi) * x.w + wi) * x.ld + x.off + cg * VEC);
+        }
+#pragma unroll
+      for (int kh = 0; kh < (KC ? KC : 1); ++kh)
+#pragma unroll
+        for (int kw = 0; kw < (KC ? KC : 1); ++kw) {
+          const int hi = (int)ho * s - p + kh, wi = (int)wo * s - p + kw;
+          const bool in = (unsigned)hi < (unsigned)x.h && (unsigned)wi < (unsigned)x.w;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float f = v[kh * (KC ? KC : 1) + kw].get(i);
+            if (in && (first || f > best[i] || f != f)) { best[i] = f; arg[i] = kh * k + kw; }
+          }
+          first = first && !in;
+        }
+    } else
     for (int kh = 0; kh < k; ++kh) {
       const int hi = (int)ho * s - p + kh;
       if ((unsigned)hi >= (unsigned)x.h) continue;
@@ -79,6 +106,42 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(FM dy, const uint8_t* 
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (KC == 3 && SC == 2 && PC == 1) {
+      // (3, 2, 1): an input row belongs to window rows ho0 = (hi+1-kh0)/2 with kh0 = (hi+1)&1 and, when kh0 == 0, also to
+      // ho0-1 with kh = 2 -- at most 2 x 2 windows.  All four (gradient, argmax) pairs are loaded from clamped coordinates,
+      // invalid ones are dropped afterwards: no branch around a load
+      const int kh0 = ((int)hi + 1) & 1, kw0 = ((int)wi + 1) & 1;
+      const int ho0 = ((int)hi + 1 - kh0) >> 1, wo0 = ((int)wi + 1 - kw0) >> 1;
+      Vec16<T> g[4];
+      uint32_t alo[4], ahi[4];
+      bool ok[4];
+      int code[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int ho = ho0 - a, wo = wo0 - b, kh = kh0 + 2 * a, kw = kw0 + 2 * b;
+          ok[2 * a + b] = kh < 3 && kw < 3 && ho >= 0 && wo >= 0 && ho < dy.h && wo < dy.w;
+          code[2 * a + b] = kh * 3 + kw;
+          const int hc = ho < 0 ? 0 : (ho >= dy.h ? dy.h - 1 : ho), wc = wo < 0 ? 0 : (wo >= dy.w ? dy.w - 1 : wo);
+          const int64_t opix = ((int64_t)nt * dy.h + hc) * dy.w + wc;
+          g[2 * a + b].load(static_cast<const T*>(dy.p) + opix * dy.ld + dy.off + cg * VEC);
+          const uint8_t* ap = argmax + opix * c + cg * VEC;
+          if (VEC == 8) {
+            const uint2 a2 = *reinterpret_cast<const uint2*>(ap);
+            alo[2 * a + b] = a2.x; ahi[2 * a + b] = a2.y;
+          } else {
+            alo[2 * a + b] = *reinterpret_cast<const uint32_t*>(ap); ahi[2 * a + b] = 0;
+          }
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const uint32_t am = ((i < 4 ? alo[q] : ahi[q]) >> (8 * (i & 3))) & 0xFFu;
+          if (ok[q] && am == (uint32_t)code[q]) acc[i] += g[q].get(i);
+        }
+    } else
     // windows (ho, wo) that contain (hi, wi): ho*s - p + kh == hi
     for (int kh = 0; kh < k; ++kh) {
       const int num_h = (int)hi + p - kh;
