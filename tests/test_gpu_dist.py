@@ -1,0 +1,66 @@
+"""The multi-rank step on the real GPU schedule: two processes share cuda:0 (one MI355X per test box), gradients are
+exchanged with gloo on CUDA tensors -- the collective is not what is tested; the four-lane backward, the segment cuts and
+the comm stream's event waits on every lane are.  Both ranks must end the step with identical weights."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from video_classification_amd import arch, dist as sdist
+    from video_classification_amd.slowfast import SlowFast
+    from video_classification_amd.train import TrainStep
+    torch.cuda.set_device(0)
+    sdist.init_process_group_from_env("gloo")
+    spec = arch.ref_spec(num_class=5, depth=18, head_pool_kernels=((2, 1, 1), (2, 1, 1)))
+    m = SlowFast(spec, dtype=torch.bfloat16, device="cuda:0", seed=3)          # same seed: same weights
+    eng = m.engine
+    g = torch.Generator().manual_seed(100)
+    clips = torch.randn(world * 2, 4, 21, 32, 32, generator=g)
+    labels = torch.randint(0, 5, (world * 2,), generator=g)
+    idx = sdist.shard_indices(world * 2, rank, world, epoch_seed=0, shuffle=False)
+    x = clips[idx].to("cuda:0").permute(0, 2, 1, 3, 4)
+    red = sdist.GradReducer(eng.G, bucket_mb=0.25)
+    step = TrainStep(eng, lr=1e-2, use_graph=False, reducer=red, overlap_segments=4)
+    m.train()
+    for _ in range(3):
+        step(x[:, 0:5], x[:, 5:20], labels[idx].to("cuda:0"))
+    torch.cuda.synchronize()
+    cover = torch.zeros(eng.arena_numel, dtype=torch.int32)
+    for off, n in red.reduced:
+        cover[off:off + n] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    assert len(eng.lane_streams()) == 4
+    torch.save({"P": eng.P.data.cpu(), "G": eng.G.cpu(), "loss": float(step.loss[0])}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_share_the_gpu(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / "rank0.pt")
+    b = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(a["G"], b["G"])          # the summed gradients are identical on both ranks
+    assert torch.equal(a["P"], b["P"])          # so are the weights after three steps
+    assert torch.isfinite(a["P"]).all() and a["loss"] == a["loss"]
