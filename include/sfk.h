@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 2
+#define SFK_ABI_VERSION 3
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -217,13 +217,17 @@ int sfk_bn_stats(const sfk_fmap* y, float* partials, int32_t max_parts, int32_t*
                  sfk_stream_t stream);
 
 /* a = act( y*scale + shift + shortcut ),  shortcut = 0 | res | res*res_scale + res_shift ; act = ReLU if relu.
- * (stem / bottleneck norm+act, ResBlock "x + branch2(x)" then ReLU.) */
+ * (stem / bottleneck norm+act, ResBlock "x + branch2(x)" then ReLU.)
+ * relu_bits (optional, needs relu): the ReLU mask as one bit per element, byte [pixel][c / V] holding the V sign bits of
+ * channel group g (V = 8 for bf16, 4 for f32; bit i = (a[pixel][g*V + i] > 0)) -- 1/16 of a bf16 map.  The backward of
+ * a block output reads these instead of the activation (sfk_bn_bwd_reduce). */
 int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
                  const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
-                 sfk_stream_t stream);
+                 uint8_t* relu_bits, sfk_stream_t stream);
 
 /* Backward of a = act(bn(y) [+ shortcut]) given dA:
- *   dz = dA * mask,   mask = (mask_src > 0) if mask_src, else (y*scale+shift > 0) if relu, else 1
+ *   dz = dA * mask,   mask = relu_bits (as written by sfk_bn_apply) if given, else (mask_src > 0) if mask_src,
+ *                     else (y*scale+shift > 0) if relu, else 1
  *   reduce: partials[nparts][c][2] = (sum dz, sum dz*xhat), xhat = (y-mean)*invstd; if dz_out: dz_out = dz
  *   finalize: dgamma (+)= sum dz*xhat, dbeta (+)= sum dz; coef[c][3] = (gamma*invstd, sum dz/count, sum dz*xhat/count)
  *   apply: dy = coef0 * (dz - coef1 - xhat*coef2)
@@ -231,7 +235,7 @@ int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
 int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                       const float* invstd, const float* scale, const float* shift, int32_t relu,
                       const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
-                      sfk_stream_t stream);
+                      const uint8_t* relu_bits, sfk_stream_t stream);
 int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                         const float* invstd, float* dgamma, float* dbeta, float* coef, float* workspace,
                         sfk_stream_t stream); /* workspace: as sfk_bn_finalize */

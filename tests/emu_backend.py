@@ -206,7 +206,11 @@ class EmuBackend:
             pt[0, :, 1] = (v * v).sum(0)
         return run, 1
 
-    def bn_apply(self, y, scale, shift, res, res_scale, res_shift, relu, out):
+    @staticmethod
+    def _vec(y):
+        return 8 if y.dtype == torch.bfloat16 else 4
+
+    def bn_apply(self, y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=None):
         def run(stream):
             c = y.c
             v = y.view5().float() * scale[:c] + shift[:c]
@@ -216,6 +220,11 @@ class EmuBackend:
                     r = r * res_scale[:c] + res_shift[:c]
                 v = v + r
             if relu:
+                if relu_bits is not None:                       # byte [pixel][group] = sign bits of the group's channels
+                    vec = self._vec(y)
+                    pos = (v > 0).reshape(-1, c // vec, vec).to(torch.int32)
+                    wts = (1 << torch.arange(vec, dtype=torch.int32, device=pos.device))
+                    relu_bits[: pos.shape[0] * (c // vec)] = (pos * wts).sum(-1).to(torch.uint8).reshape(-1)
                 v = v.clamp_min(0)
             out.view5().copy_(v.to(out.dtype))
         return run
@@ -231,10 +240,19 @@ class EmuBackend:
             dz = dz * ((yv * scale[:c] + shift[:c]) > 0)
         return dz, yv
 
-    def bn_bwd_reduce(self, da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts):
+    def bn_bwd_reduce(self, da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts,
+                      relu_bits=None):
         def run(stream):
             c = y.c
-            dz, yv = self._dz(da, y, mask_src, scale, shift, relu)
+            if relu_bits is not None:
+                assert mask_src is None
+                vec = self._vec(y)
+                b = relu_bits[: y.pixels * (c // vec)].to(torch.int32).reshape(-1, c // vec, 1)
+                m = ((b >> torch.arange(vec, dtype=torch.int32, device=b.device)) & 1).reshape(-1, c)
+                yv = y.view5().float()
+                dz = da.view5().float() * m.reshape(yv.shape).float()
+            else:
+                dz, yv = self._dz(da, y, mask_src, scale, shift, relu)
             xhat = (yv - mean[:c]) * invstd[:c]
             pt = partials[: c * 2].view(1, c, 2)
             pt[0, :, 0] = dz.reshape(-1, c).sum(0)

@@ -308,6 +308,7 @@ def test_batchnorm_forward_backward(hip, dtype, c):
         bparts = f(2048 * c * 2)
         run, nb = be.bn_bwd_reduce(da, y, out, mean, invstd, scale, shift, True, da, bparts, 2048)
         run(st)
+        bp1 = bparts[: nb * c * 2].clone()
         dgamma, dbeta, coef = f(c), f(c), f(c * 3)
         be.bn_bwd_finalize(bparts, nb, c, px, gamma.to(dev), invstd, dgamma, dbeta, coef)(st)
         dy = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
@@ -321,16 +322,39 @@ def test_batchnorm_forward_backward(hip, dtype, c):
         be.bn_bwd_apply(da2, y, None, mean, invstd, scale, shift, True, coef2, da2)(st)   # in place
         ev_s, ev_h = f(c), f(c)
         be.bn_eval_coeffs(gamma.to(dev), beta.to(dev), rm, rv, 1e-5, c, ev_s, ev_h)(st)
+        # the same block-output backward through the 1-bit ReLU mask bn_apply can leave behind
+        vec = 8 if dtype == torch.bfloat16 else 4
+        bits = torch.zeros(px * c // vec + 16, dtype=torch.uint8, device=dev)
+        out3 = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
+        be.bn_apply(y, scale, shift, res, None, None, True, out3, relu_bits=bits)(st)
+        da3 = FMap(mk((px * c,), dtype, torch.Generator().manual_seed(5)).to(dev), n, t, h, w, c)
+        bparts3 = f(2048 * c * 2)
+        run, nb3 = be.bn_bwd_reduce(da3, y, None, mean, invstd, scale, shift, True, da3, bparts3, 2048, relu_bits=bits)
+        run(st)
+        assert nb3 == nb
         return dict(mean=mean, invstd=invstd, scale=scale, shift=shift, rm=rm, rv=rv, out=out.buf, out2=out2.buf,
                     dz=da.buf, dgamma=dgamma, dbeta=dbeta, dy=dy.buf, dy2=da2.buf, ev_s=ev_s, ev_h=ev_h,
-                    nbt=nbt.float())
+                    nbt=nbt.float(), out3=out3.buf, dz3=da3.buf, bits=bits, bparts=bp1,
+                    bparts3=bparts3[: nb * c * 2])
 
     a = side(emu, yc, rc, "cpu", 0)
     b = side(hip, yg, rg, DEV, stream())
     torch.cuda.synchronize()
     for kname in a:
-        tol = TOL[dtype] if kname in ("out", "out2", "dz", "dy", "dy2") else 2e-4
+        if kname in ("bits", "bparts", "bparts3"):
+            continue
+        tol = TOL[dtype] if kname in ("out", "out2", "dz", "dy", "dy2", "out3", "dz3") else 2e-4
         assert rel_err(b[kname].float().cpu(), a[kname].float()) < tol, kname
+    # the bitmap route is the mask_src route bit for bit (outputs, dz and the partial sums), and the bytes are the
+    # packed signs of the activation
+    for side_ in (a, b):
+        assert torch.equal(side_["out3"], side_["out"]) and torch.equal(side_["dz3"], side_["dz"])
+        vec = 8 if dtype == torch.bfloat16 else 4
+        pos = (side_["out"].float() > 0).reshape(-1, vec).to(torch.int32)
+        packed = (pos << torch.arange(vec, dtype=torch.int32, device=pos.device)).sum(-1).to(torch.uint8)
+        assert torch.equal(side_["bits"][: packed.numel()], packed)
+        assert int(side_["bits"][packed.numel():].sum()) == 0
+    assert torch.equal(b["bparts3"], b["bparts"])
     # and against torch's own BatchNorm for the statistics
     v = yc.view5().float().reshape(-1, c)
     assert rel_err(b["mean"].cpu(), v.mean(0)) < 1e-5

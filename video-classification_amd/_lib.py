@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsfk.so")
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 2        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 3        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -203,9 +203,9 @@ SIGNATURES = {
     "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
     "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
-    "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV],
+    "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV, _PV],
     "sfk_bn_bwd_reduce": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _P_FMAP, _PF, _I32,
-                          C.POINTER(C.c_int32), _PV],
+                          C.POINTER(C.c_int32), _PV, _PV],
     "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_bwd_apply": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _PF, _P_FMAP, _PV],
     "sfk_maxpool_fwd": [_P_FMAP, _P_FMAP, _PV, _I32, _I32, _I32, _PV],
@@ -450,24 +450,33 @@ class HipBackend:
             parts = min(parts, max_parts)
         return max(1, parts)
 
-    def bn_apply(self, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap):
+    def bn_apply(self, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap,
+                 relu_bits=None):
+        """relu_bits: optional uint8 tensor of pixels * c / V bytes (V = 8 bf16, 4 f32) that receives the ReLU mask."""
         fy, fo = _c_fmap(y), _c_fmap(out)
         fr = _c_fmap(res) if res is not None else None
+        if relu_bits is not None:
+            vec = 8 if y.dtype == torch.bfloat16 else 4
+            assert relu_bits.dtype == torch.uint8 and relu_bits.numel() >= y.pixels * (y.c // vec)
         return self._plain("sfk_bn_apply", C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fr) if fr else None,
-                           _ptr(res_scale), _ptr(res_shift), 1 if relu else 0, C.byref(fo),
-                           keep=(fy, fo, fr, y, out, res, scale, shift, res_scale, res_shift))
+                           _ptr(res_scale), _ptr(res_shift), 1 if relu else 0, C.byref(fo), _ptr(relu_bits),
+                           keep=(fy, fo, fr, y, out, res, scale, shift, res_scale, res_shift, relu_bits))
 
     def bn_bwd_reduce(self, da: FMap, y: FMap, mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool,
-                      dz_out: Optional[FMap], partials, max_parts):
-        """returns (run, nparts)"""
+                      dz_out: Optional[FMap], partials, max_parts, relu_bits=None):
+        """returns (run, nparts); relu_bits: the mask bn_apply wrote (then mask_src must be None)."""
+        if relu_bits is not None:
+            vec = 8 if y.dtype == torch.bfloat16 else 4
+            assert relu_bits.dtype == torch.uint8 and relu_bits.numel() >= y.pixels * (y.c // vec)
         fa, fy = _c_fmap(da), _c_fmap(y)
         fm = _c_fmap(mask_src) if mask_src is not None else None
         fz = _c_fmap(dz_out) if dz_out is not None else None
         np_ = C.c_int32(0)
         run = self._plain("sfk_bn_bwd_reduce", C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean),
                           _ptr(invstd), _ptr(scale), _ptr(shift), 1 if relu else 0, C.byref(fz) if fz else None,
-                          _ptr(partials), max_parts, C.byref(np_),
-                          keep=(fa, fy, fm, fz, np_, da, y, mask_src, dz_out, mean, invstd, scale, shift, partials))
+                          _ptr(partials), max_parts, C.byref(np_), _ptr(relu_bits),
+                          keep=(fa, fy, fm, fz, np_, da, y, mask_src, dz_out, mean, invstd, scale, shift, partials,
+                                relu_bits))
         return run, self._dry_parts(y, max_parts)
 
     def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef, workspace=None):

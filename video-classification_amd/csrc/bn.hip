@@ -209,10 +209,12 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ------------------------------------------------------------------ forward apply
 // RES: 0 none, 1 plain residual, 2 residual with its own scale/shift (projection shortcut's BN)
+// relu_bits (optional, RELU only): one bit per output element, byte [pixel][channel group] = the VEC sign bits of the
+// group -- 1/16 of the bf16 map.  The backward of act(bn(y) + shortcut) reads it instead of the activation itself.
 template <typename T, int RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
                                                        const float* scale, const float* shift,
-                                                       const float* rscale, const float* rshift) {
+                                                       const float* rscale, const float* rshift, uint8_t* relu_bits) {
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
@@ -231,25 +233,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
     Vec16<T> v, r, o;
     v.load(yp + p * y.ld);
     if (RES) r.load(rp + p * res.ld);
+    uint32_t bits = 0;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float f = v.get(i) * sc[i] + sh[i];
       if (RES == 1) f += r.get(i);
       if (RES == 2) f += r.get(i) * rsc[i] + rsh[i];
-      if (RELU) f = f > 0.f ? f : 0.f;
+      if (RELU) {
+        bits |= (f > 0.f ? 1u : 0u) << i;
+        f = f > 0.f ? f : 0.f;
+      }
       o.set(i, f);
     }
     o.store(op + p * out.ld);
+    if (RELU && relu_bits) relu_bits[p * cgs + cm.cg] = (uint8_t)bits;
   }
 }
 
 // ------------------------------------------------------------------ backward
-// MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0)
+// MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0), 3 mask = relu_bits of bn_apply
 template <typename T, int MASK, bool WRITE_DZ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc, FM dzo, int64_t pixels, int c,
                                                             const float* mean, const float* invstd,
                                                             const float* scale, const float* shift,
-                                                            float* partials) {
+                                                            float* partials, const uint8_t* relu_bits) {
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
@@ -273,12 +280,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
       d.load(dap + p * da.ld);
       v.load(yp + p * y.ld);
       if (MASK == 2) m.load(mp + p * msrc.ld);
+      uint32_t bits = 0;
+      if (MASK == 3) bits = relu_bits[p * cgs + cm.cg];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float yv = v.get(i);
         float dz = d.get(i);
         if (MASK == 1) dz = (yv * sc[i] + sh[i] > 0.f) ? dz : 0.f;
         if (MASK == 2) dz = (m.get(i) > 0.f) ? dz : 0.f;
+        if (MASK == 3) dz = ((bits >> i) & 1u) ? dz : 0.f;
         if (WRITE_DZ) z.set(i, dz);
         s1[i] += dz;
         s2[i] += dz * ((yv - mu[i]) * is[i]);
@@ -398,13 +408,13 @@ extern "C" int sfk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 namespace {
 template <typename T>
 int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
-                 const float* rs, const float* rb, int relu, const sfk_fmap* out, hipStream_t s) {
+                 const float* rs, const float* rb, int relu, const sfk_fmap* out, uint8_t* bits, hipStream_t s) {
   const int64_t px = sfk_fmap_pixels(y);
   int np;
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np), blk(256);
   const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
   const int mode = !res ? 0 : (rs ? 2 : 1);
-#define SFK_APPLY(R, A) hipLaunchKernelGGL((bn_apply_kernel<T, R, A>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb)
+#define SFK_APPLY(R, A) hipLaunchKernelGGL((bn_apply_kernel<T, R, A>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits)
   if (relu) {
     if (mode == 0) SFK_APPLY(0, true); else if (mode == 1) SFK_APPLY(1, true); else SFK_APPLY(2, true);
   } else {
@@ -418,14 +428,15 @@ int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
 
 extern "C" int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
                             const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
-                            sfk_stream_t stream) {
+                            uint8_t* relu_bits, sfk_stream_t stream) {
+  if (relu_bits && !relu) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(y) || !sfk_fmap_ok(out) || !scale || !shift || !same_shape(y, out)) return SFK_ERR_INVALID;
   if (res && (!sfk_fmap_ok(res) || !same_shape(y, res))) return SFK_ERR_INVALID;
   if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return SFK_ERR_INVALID;
   if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res))) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return y->dtype == SFK_BF16 ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, s)
-                              : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, s);
+  return y->dtype == SFK_BF16 ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, s)
+                              : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, s);
 }
 
 namespace {
@@ -441,17 +452,18 @@ int check_bwd(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, c
 template <typename T>
 int launch_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, const float* mean,
                       const float* invstd, const float* scale, const float* shift, int relu,
-                      const sfk_fmap* dzo, float* partials, int max_parts, int* nparts_out, hipStream_t s) {
+                      const sfk_fmap* dzo, float* partials, int max_parts, int* nparts_out, const uint8_t* bits,
+                      hipStream_t s) {
   const int64_t px = sfk_fmap_pixels(y);
   int np;
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, max_parts, &np), blk(256);
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), z = fm_of(dzo);
-  const int mask = ms ? 2 : (relu ? 1 : 0);
-#define SFK_RED(M, W) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials)
+  const int mask = bits ? 3 : (ms ? 2 : (relu ? 1 : 0));
+#define SFK_RED(M, W) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits)
   if (dzo) {
-    if (mask == 0) SFK_RED(0, true); else if (mask == 1) SFK_RED(1, true); else SFK_RED(2, true);
+    if (mask == 0) SFK_RED(0, true); else if (mask == 1) SFK_RED(1, true); else if (mask == 2) SFK_RED(2, true); else SFK_RED(3, true);
   } else {
-    if (mask == 0) SFK_RED(0, false); else if (mask == 1) SFK_RED(1, false); else SFK_RED(2, false);
+    if (mask == 0) SFK_RED(0, false); else if (mask == 1) SFK_RED(1, false); else if (mask == 2) SFK_RED(2, false); else SFK_RED(3, false);
   }
 #undef SFK_RED
   SFK_CHECK_LAUNCH();
@@ -479,16 +491,18 @@ int launch_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, 
 extern "C" int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, int32_t relu,
                                  const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
-                                 sfk_stream_t stream) {
-  const int st = check_bwd(da, y, mask_src, mean, invstd, scale, shift, relu);
+                                 const uint8_t* relu_bits, sfk_stream_t stream) {
+  if (relu_bits && mask_src) return SFK_ERR_INVALID;
+  const int st = check_bwd(da, y, mask_src, mean, invstd, (relu_bits ? nullptr : scale), (relu_bits ? nullptr : shift),
+                           relu_bits ? 0 : relu);
   if (st != SFK_OK) return st;
   if (!partials || max_parts <= 0 || !nparts_out) return SFK_ERR_INVALID;
   if (dz_out && (!sfk_fmap_ok(dz_out) || !same_shape(da, dz_out))) return SFK_ERR_INVALID;
   if (dz_out && !sfk_fmap_vec_ok(dz_out)) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return y->dtype == SFK_BF16
-             ? launch_bwd_reduce<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, s)
-             : launch_bwd_reduce<float>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, s);
+             ? launch_bwd_reduce<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, relu_bits, s)
+             : launch_bwd_reduce<float>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, relu_bits, s);
 }
 
 extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,

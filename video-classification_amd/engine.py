@@ -137,6 +137,8 @@ class Engine:
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
+        self.relu_bits = os.environ.get("SFK_RELU_BITS", "1") != "0"       # block-output ReLU masks kept as bitmaps
+        self.kvec = 8 if self.dtype == torch.bfloat16 else 4               # channels per 16-byte lane of the BN kernels
         # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
         # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
         self.deterministic_wgrad = os.environ.get("SFK_WGWS", "0") == "1"
@@ -376,14 +378,17 @@ class Engine:
             pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, L.rm, L.rv, self.spec.bn_eps, L.c, scale, shift))
         return y, scale, shift, rec
 
-    def _apply(self, pl: Plan, y: FMap, scale, shift, res, res_scale, res_shift, relu: bool, out: FMap):
+    def _apply(self, pl: Plan, y: FMap, scale, shift, res, res_scale, res_shift, relu: bool, out: FMap, bits=None):
         esz = 2 if self.dtype == torch.bfloat16 else 4
-        pl.fwd.append(self.be.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out), kind="bn_apply",
-                      bytes=float(y.pixels * y.c * esz * (2 + (1 if res is not None else 0))))
+        pl.fwd.append(self.be.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=bits),
+                      kind="bn_apply",
+                      bytes=float(y.pixels * y.c * esz * (2 + (1 if res is not None else 0))
+                                  + (y.pixels * y.c // self.kvec if bits is not None else 0)))
 
     def _bn_bwd(self, pl: Plan, rec: _UnitRec, da: FMap, tag: str, relu: bool, mask_src: Optional[FMap],
-                dz_inplace: bool, dy: FMap, reduced=None):
+                dz_inplace: bool, dy: FMap, reduced=None, bits=None):
         """BatchNorm(+ReLU) backward of one unit: da -> dy (may alias da), accumulates dgamma/dbeta.
+        bits: the ReLU mask the forward bn_apply left (1 bit per element), read instead of mask_src (needs dz_inplace).
         reduced = (partials, rows): the pass that produced da already masked it (da holds dz) and left the partial
         sums (fused epilogue, _dgrad(fuse=...)), so the reduce kernel is skipped."""
         L = rec.L
@@ -395,10 +400,14 @@ class Engine:
             dz_inplace = True
         else:
             parts = self._buf(f"bparts.{tag}", MAX_PARTS * L.c * 2, torch.float32)
+            if bits is not None:
+                assert dz_inplace
+                mask_src = None
             run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
-                                             da if dz_inplace else None, parts, MAX_PARTS)
+                                             da if dz_inplace else None, parts, MAX_PARTS, relu_bits=bits)
             pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
-                          bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0)))
+                          bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0))
+                          + (rec.y.pixels * L.c // self.kvec if bits is not None else 0))
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                               self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
                                               self._fold_ws(tag, L.c)))
@@ -571,11 +580,13 @@ class Engine:
         self._apply(pl, yb, sb, hb, None, None, None, True, ab)
         yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n)
         assert (yc.t, yc.h, yc.w, yc.c) == (out.t, out.h, out.w, out.c)
+        # the block output's ReLU mask, 1 bit per element, for the backward pass (which otherwise re-reads `out`)
+        bits = self._buf(f"relubits.{tag}", out.pixels * (out.c // self.kvec), torch.uint8) if (train and self.relu_bits) else None
         if blk.branch1 is not None:
-            self._apply(pl, yc, sc, hc, y1, s1, h1, True, out)
+            self._apply(pl, yc, sc, hc, y1, s1, h1, True, out, bits)
         else:
-            self._apply(pl, yc, sc, hc, x, None, None, True, out)
-        return (blk, tag, x, out, rec1, reca, recb, recc)
+            self._apply(pl, yc, sc, hc, x, None, None, True, out, bits)
+        return (blk, tag, x, out, rec1, reca, recb, recc, bits)
 
     def _block_bwd(self, pl, brec, d_out: FMap, reduced_c=None, prev=None):
         """d_out: gradient w.r.t. the block output (clobbered).  returns (gradient w.r.t. the block input, reduced)
@@ -583,11 +594,11 @@ class Engine:
         prev: the record of the block that feeds this one through an identity path -- its final-BatchNorm reduce is
         folded into this block's last data-gradient pass, whose result IS the gradient of prev's output; `reduced`
         is then what to hand to prev's _block_bwd."""
-        blk, tag, x, out, rec1, reca, recb, recc = brec
+        blk, tag, x, out, rec1, reca, recb, recc, bits = brec
         n = x.n
         # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
         dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
-        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c)
+        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
         self._wgrad(pl, recc, dyc)
         dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
         red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
