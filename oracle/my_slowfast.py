@@ -141,6 +141,20 @@ def mini_slowfast(num_class: int = 7, *, ref_style: bool = True, depth: int = 18
                               head_pool_kernel_sizes=hp)
 
 
+def slow_r50(num_class: int = 400, input_channels: int = 5, depth: int = 50, head_pool=(8, 7, 7)) -> nn.Module:
+    """The reference's `res3d` network: hub `slow_r50` with its stem conv swapped for
+    Conv3d(5, 64, (1,7,7), stride (1,2,2), padding (0,3,3), bias=False) ((deprecated)/train_3dresnet.py:47-51,
+    train.py:79-89).  depth=18 + a small head pool give the mini version the parity tests use."""
+    return pv.create_resnet(input_channel=input_channels, model_depth=depth, model_num_class=num_class,
+                            stem_conv_kernel_size=(1, 7, 7), head_pool_kernel_size=tuple(head_pool))
+
+
+def prepare_res3d_data(clips: torch.Tensor) -> torch.Tensor:
+    """(N,T,C,S,S) dataset tensor -> (N,C,T,S,S) view (train.py:85-89; the deprecated trainer feeds the 5 BGR+UV
+    channels, train_3dresnet.py:86-93)."""
+    return clips.permute(0, 2, 1, 3, 4)
+
+
 def prepare_slowfast_data(clips: torch.Tensor) -> List[torch.Tensor]:
     """(N,T,21,S,S) dataset tensor -> [BGR+UV (N,5,T,S,S), flow (N,15,T,S,S)] views; the depth channel (20)
     is dropped (train.py:125-145)."""

@@ -370,3 +370,39 @@ def create_slowfast(*, slowfast_channel_reduction_ratio=(8,), slowfast_conv_chan
                                         activation=head_activation,
                                         output_with_global_average=head_output_with_global_average))
     return Net(blocks=nn.ModuleList(blocks))
+
+
+# --------------------------------------------------------------------------- create_resnet (single pathway; A1.1)
+def create_resnet(*, input_channel=3, model_depth=50, model_num_class=400, dropout_rate=0.5, norm=nn.BatchNorm3d,
+                  activation=nn.ReLU, stem_dim_out=64, stem_conv_kernel_size=(3, 7, 7), stem_conv_stride=(1, 2, 2),
+                  stem_pool=nn.MaxPool3d, stem_pool_kernel_size=(1, 3, 3), stem_pool_stride=(1, 2, 2),
+                  stage_conv_a_kernel_size=((1, 1, 1), (1, 1, 1), (3, 1, 1), (3, 1, 1)),
+                  stage_conv_b_kernel_size=((1, 3, 3),) * 4, stage_spatial_h_stride=(1, 2, 2, 2),
+                  stage_temporal_stride=(1, 1, 1, 1), head_pool=nn.AvgPool3d, head_pool_kernel_size=(4, 7, 7),
+                  head_output_size=(1, 1, 1), head_activation=None, head_output_with_global_average=True):
+    """pytorchvideo.models.resnet.create_resnet (third-party, absent here; restated from its published structure):
+    blocks = [stem, res2, res3, res4, res5, head]; the head (create_res_basic_head) owns its AvgPool3d, stride 1.
+    The reference reaches it as torch.hub `slow_r50` ((deprecated)/train_3dresnet.py:48, train.py:80):
+    create_resnet(stem_conv_kernel_size=(1,7,7), head_pool_kernel_size=(8,7,7), model_depth=50)."""
+    depths = _STAGE_DEPTHS[model_depth]
+    blocks = [create_res_basic_stem(in_channels=input_channel, out_channels=stem_dim_out,
+                                    conv_kernel_size=stem_conv_kernel_size, conv_stride=stem_conv_stride,
+                                    conv_padding=_half(stem_conv_kernel_size), pool=stem_pool,
+                                    pool_kernel_size=stem_pool_kernel_size, pool_stride=stem_pool_stride,
+                                    pool_padding=_half(stem_pool_kernel_size), norm=norm, activation=activation)]
+    dim_in, dim_out = stem_dim_out, stem_dim_out * 4
+    for idx, depth in enumerate(depths):
+        ka, kb = stage_conv_a_kernel_size[idx], stage_conv_b_kernel_size[idx]
+        ss, ts = stage_spatial_h_stride[idx], stage_temporal_stride[idx]
+        blocks.append(create_res_stage(
+            depth=depth, dim_in=dim_in, dim_inner=dim_out // 4, dim_out=dim_out, bottleneck=create_bottleneck_block,
+            conv_a_kernel_size=ka, conv_a_stride=(ts, 1, 1), conv_a_padding=_half(ka), conv_b_kernel_size=kb,
+            conv_b_stride=(1, ss, ss), conv_b_padding=tuple(k // 2 for k in kb), conv_b_num_groups=1,
+            conv_b_dilation=(1, 1, 1), norm=norm, activation=activation))
+        dim_in, dim_out = dim_out, dim_out * 2
+    blocks.append(create_res_basic_head(
+        in_features=dim_in, out_features=model_num_class,
+        pool=head_pool(kernel_size=tuple(head_pool_kernel_size), stride=(1, 1, 1), padding=(0, 0, 0)),
+        output_size=head_output_size, dropout_rate=dropout_rate, activation=head_activation,
+        output_with_global_average=head_output_with_global_average))
+    return Net(blocks=nn.ModuleList(blocks))

@@ -6,6 +6,9 @@ Two parametrisations of the same wiring:
                   ModuleLists (+ dead residual/res_unit parameters), head pools (4,2,2) stride 1.
   canonical_spec  SlowFast-R50 8x8 of BASELINE.json's metric: T_fast = 4 T_slow, fast stem (5,7,7), fusion
                   (7,1,1)/(4,1,1), head pools (8,7,7)/(32,7,7)  ((deprecated)/(torchvideo)train.py:44-71,249).
+  slow_r50_spec   the reference's `res3d` model: pytorchvideo slow_r50 with a 5-channel (1,7,7) stem
+                  ((deprecated)/train_3dresnet.py:47-51, train.py:79-89) -- ONE pathway: the slow pathway's wiring
+                  without lateral fusion, keys `blocks.0.conv`, `blocks.<s>.res_blocks.<i>...`, `blocks.5.proj`.
 Checkpoint key scheme: pytorchvideo's, pinned by train.py:94-108.
 """
 from __future__ import annotations
@@ -40,8 +43,12 @@ class SlowFastSpec:
     bn_momentum: float = 0.1
 
     @property
+    def pathways(self) -> int:
+        return len(self.input_channels)
+
+    @property
     def reduction(self) -> int:
-        return self.stem_dim_outs[0] // self.stem_dim_outs[1]
+        return self.stem_dim_outs[0] // self.stem_dim_outs[1] if self.pathways == 2 else 1
 
     @property
     def depths(self) -> Tuple[int, int, int, int]:
@@ -60,6 +67,15 @@ def canonical_spec(num_class: int = 400, depth: int = 50, input_channels=(3, 3),
                    head_pool_kernels=((8, 7, 7), (32, 7, 7))) -> SlowFastSpec:
     return SlowFastSpec(num_class=num_class, input_channels=tuple(input_channels), depth=depth,
                         head_pool_kernels=tuple(map(tuple, head_pool_kernels)))
+
+
+def slow_r50_spec(num_class: int = 400, input_channels: int = 5, depth: int = 50,
+                  head_pool_kernel: Triple = (8, 7, 7)) -> SlowFastSpec:
+    """pytorchvideo `slow_r50` = create_resnet(stem (1,7,7), conv_a ((1,1,1),(1,1,1),(3,1,1),(3,1,1)), head pool
+    (8,7,7), dropout 0.5) with the reference's stem swap to `input_channels` (train_3dresnet.py:49)."""
+    return SlowFastSpec(num_class=num_class, input_channels=(input_channels,), stem_dim_outs=(64,),
+                        stem_kernels=((1, 7, 7),), conv_a_kernels=(((1, 1, 1), (1, 1, 1), (3, 1, 1), (3, 1, 1)),),
+                        depth=depth, fuse=False, fusion_ratio=0, head_pool_kernels=(tuple(head_pool_kernel),))
 
 
 # ----------------------------------------------------------------------------- layer records
@@ -96,15 +112,17 @@ class Wiring:
     fusions: List[Optional[ConvBN]]      # after blocks.0 .. blocks.3 (None when fuse=False)
     dead: List[DeadParam] = field(default_factory=list)
     head_in: int = 0
+    head_key: str = "blocks.6.proj"
 
     def all_convbn(self) -> List[ConvBN]:
         out: List[ConvBN] = []
-        for p in range(2):
+        np_ = len(self.stems)
+        for p in range(np_):
             out.append(self.stems[p])
         if self.fusions[0] is not None:
             out.append(self.fusions[0])
         for si, stage in enumerate(self.stages):
-            for p in range(2):
+            for p in range(np_):
                 for b in stage[p]:
                     if b.branch1 is not None:
                         out.append(b.branch1)
@@ -120,10 +138,15 @@ def _half(k: Triple) -> Triple:
 
 def build_wiring(spec: SlowFastSpec) -> Wiring:
     red = spec.reduction
+    np_ = spec.pathways
+    assert np_ in (1, 2) and (np_ == 2 or not spec.fuse)
+
+    def path(p: int) -> str:          # create_slowfast wraps every stage in MultiPathWayWithFuse, create_resnet does not
+        return f".multipathway_blocks.{p}" if np_ == 2 else ""
     stems = []
-    for p in range(2):
+    for p in range(np_):
         k = spec.stem_kernels[p]
-        stems.append(ConvBN(f"blocks.0.multipathway_blocks.{p}.conv", f"blocks.0.multipathway_blocks.{p}.norm",
+        stems.append(ConvBN(f"blocks.0{path(p)}.conv", f"blocks.0{path(p)}.norm",
                             ConvGeom(spec.input_channels[p], spec.stem_dim_outs[p], k, (1, 2, 2), _half(k)),
                             is_stem=True))
     dead: List[DeadParam] = []
@@ -167,13 +190,13 @@ def build_wiring(spec: SlowFastSpec) -> Wiring:
         dims_out = (dim_out_s, dim_out_s // red)
         ss = spec.spatial_strides[si]
         stage: List[List[Block]] = []
-        for p in range(2):
+        for p in range(np_):
             ka = spec.conv_a_kernels[p][si]
             blocks: List[Block] = []
             for i in range(depth):
                 d_in = dims_in[p] if i == 0 else dims_out[p]
                 s_b = (1, ss, ss) if i == 0 else (1, 1, 1)
-                base = f"blocks.{si + 1}.multipathway_blocks.{p}.res_blocks.{i}"
+                base = f"blocks.{si + 1}{path(p)}.res_blocks.{i}"
                 proj = d_in != dims_out[p] or s_b != (1, 1, 1)
                 blocks.append(Block(
                     conv_a=ConvBN(f"{base}.branch2.conv_a", f"{base}.branch2.norm_a",
@@ -191,4 +214,6 @@ def build_wiring(spec: SlowFastSpec) -> Wiring:
             fusions.append(fusion(si + 1, dim_out_s))
         dim_in_s = dim_out_s
         dim_out_s *= 2
+    if np_ == 1:
+        return Wiring(spec, stems, stages, fusions, dead, head_in=dim_in_s, head_key="blocks.5.proj")
     return Wiring(spec, stems, stages, fusions, dead, head_in=dim_in_s + dim_in_s // red)

@@ -256,9 +256,9 @@ class Engine:
             sd[nk + ".running_mean"] = L.rm.clone()
             sd[nk + ".running_var"] = L.rv.clone()
             sd[nk + ".num_batches_tracked"] = L.nbt[0].clone()
-        sd["blocks.6.proj.weight"] = P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out].reshape(
+        sd[self.wiring.head_key + ".weight"] = P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out].reshape(
             self.fc_out, self.fc_in).clone()
-        sd["blocks.6.proj.bias"] = P[self.fc_b_off:self.fc_b_off + self.fc_out].clone()
+        sd[self.wiring.head_key + ".bias"] = P[self.fc_b_off:self.fc_b_off + self.fc_out].clone()
         for k, v in self.dead.items():
             sd[k] = v.clone()
         return sd
@@ -292,10 +292,10 @@ class Engine:
                 v = get(nk + ".num_batches_tracked")
                 if v is not None:
                     L.nbt.fill_(int(v))
-            v = get("blocks.6.proj.weight")
+            v = get(self.wiring.head_key + ".weight")
             if v is not None:
                 P[self.fc_w_off:self.fc_w_off + self.fc_in * self.fc_out] = v.float().reshape(-1)
-            v = get("blocks.6.proj.bias")
+            v = get(self.wiring.head_key + ".bias")
             if v is not None:
                 P[self.fc_b_off:self.fc_b_off + self.fc_out] = v.float()
             for k in self.dead:
@@ -636,7 +636,8 @@ class Engine:
         be, spec, W = self.be, self.spec, self.wiring
         pl = Plan()
         self._wg_ws_need, self._wg_pending = {}, []
-        n = x_fast.shape[0]
+        NP = spec.pathways                              # 2: SlowFast; 1: the single-pathway `res3d` network (slow_r50)
+        n = x_slow.shape[0]
         # ---- refresh the compute-precision filter copies from the fp32 master arena
         #      (one launch: cast into the forward layout and, for training, the data-gradient transposes)
         if self.dtype != torch.float32 or train:
@@ -653,8 +654,7 @@ class Engine:
             w = (x5.shape[4] + 2 * g.p[2] - g.k[2]) // g.s[2] + 1
             return t, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         ts, hs, ws = stem_out(x_slow, 0, slow_t_index)
-        tf, hf, wf = stem_out(x_fast, 1, None)
-        c_s, c_f = spec.stem_dim_outs
+        c_s = spec.stem_dim_outs[0]
         fuse = spec.fuse
 
         def slow_buffer(tag, t, h, w, c, bi):
@@ -664,14 +664,17 @@ class Engine:
             return full, full.channels(0, c)
 
         cat0, s0 = slow_buffer("cat.0", ts, hs, ws, c_s, 0)
-        xf = self._fmap("xf.0", n, tf, hf, wf, c_f)
         F_, B_ = pl.fwd, pl.bwd
-        F_.sync(1, 0)                                   # fork: the fast pathway starts after the filter refresh
+        xf = None
+        if NP == 2:
+            tf, hf, wf = stem_out(x_fast, 1, None)
+            xf = self._fmap("xf.0", n, tf, hf, wf, spec.stem_dim_outs[1])
+            F_.sync(1, 0)                               # fork: the fast pathway starts after the filter refresh
         F_.cur_lane = 0
-        srec0 = self._stem_fwd(pl, 0, x_slow, slow_t_index, s0, train)
-        F_.cur_lane = 1
-        srec1 = self._stem_fwd(pl, 1, x_fast, None, xf, train)
-        stem_recs = [srec0, srec1]
+        stem_recs = [self._stem_fwd(pl, 0, x_slow, slow_t_index, s0, train)]
+        if NP == 2:
+            F_.cur_lane = 1
+            stem_recs.append(self._stem_fwd(pl, 1, x_fast, None, xf, train))
         fusion_recs = [None] * 4
         if fuse:
             fusion_recs[0] = self._fusion_fwd(pl, 0, xf, cat0.channels(c_s, cat0.c - c_s), train)
@@ -681,7 +684,7 @@ class Engine:
         xs_fulls, xfs = [cat0], [xf]
         for si in range(4):
             recs_sp = []
-            for p in range(2):
+            for p in range(NP):
                 F_.cur_lane = p
                 blocks = W.stages[si][p]
                 x = xs_full if p == 0 else xf
@@ -713,16 +716,19 @@ class Engine:
             xs_fulls.append(xs_full)
             xfs.append(xf)
         # ---- head (trunk stream; joins the fast pathway)
-        F_.sync(0, 1)
+        if NP == 2:
+            F_.sync(0, 1)
         F_.cur_lane = 0
         xs_out, xf_out = xs_full, xf
         F = self.fc_in
         feat = self._buf("feat", n * F, torch.float32)
         rate = float(spec.dropout) if train else 0.0
-        ks, kf = spec.head_pool_kernels
+        ks = spec.head_pool_kernels[0]
         pl.fwd.append(be.head_pool_fwd(xs_out, ks, rate, self.drop_seed, feat, F, 0))
-        pl.fwd.append(be.head_pool_fwd(xf_out, kf, rate, self.drop_seed, feat, F, xs_out.c))
-        assert xs_out.c + xf_out.c == F
+        if NP == 2:
+            kf = spec.head_pool_kernels[1]
+            pl.fwd.append(be.head_pool_fwd(xf_out, kf, rate, self.drop_seed, feat, F, xs_out.c))
+        assert xs_out.c + (xf_out.c if NP == 2 else 0) == F
         K = self.fc_out
         pl.logits = self._buf("logits", n * K, torch.float32)[: n * K].view(n, K)
         fcw, fcb = self._pslice(self.fc_w_off, F * K), self._pslice(self.fc_b_off, K)
@@ -737,17 +743,20 @@ class Engine:
                                 self._gslice(self.fc_b_off, K), n, F, K))
         pl.grad_marks.append((len(pl.bwd), (self.fc_w_off, self.layers[0].g_off - self.fc_w_off)))
         d_xs = self._fmap("d.cat.4", n, xs_out.t, xs_out.h, xs_out.w, xs_out.c)
-        d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
         pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
-        pl.bwd.append(be.head_pool_bwd(dfeat, F, xs_out.c, kf, rate, self.drop_seed, d_xf))
-        B_.sync(1, 0)                                   # fork
+        d_xf = None
+        if NP == 2:
+            d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
+            pl.bwd.append(be.head_pool_bwd(dfeat, F, xs_out.c, kf, rate, self.drop_seed, d_xf))
+            B_.sync(1, 0)                               # fork
         for si in range(3, -1, -1):
             # slow pathway of this stage: d_xs is the gradient of its last block's output
             B_.cur_lane = 0
             d = self._stage_bwd(pl, stage_recs[si][0], d_xs)
             d_cat = d                                   # gradient of the (concatenated) slow input of this stage
-            B_.cur_lane = 1
-            d_xf = self._stage_bwd(pl, stage_recs[si][1], d_xf)
+            if NP == 2:
+                B_.cur_lane = 1
+                d_xf = self._stage_bwd(pl, stage_recs[si][1], d_xf)
             c_prev = xs_fulls[si].c - (W.fusions[si].geom.cout if fuse else 0)
             if fuse:
                 B_.sync(1, 0)                           # the fusion's gradient comes out of the slow pathway's d_cat
@@ -755,12 +764,14 @@ class Engine:
             d_xs = d_cat.channels(0, c_prev)
         B_.cur_lane = 0
         self._stem_bwd(pl, 0, stem_recs[0], d_xs)
-        B_.cur_lane = 1
-        self._stem_bwd(pl, 1, stem_recs[1], d_xf)
-        B_.sync(0, 1)                                   # join before the optimiser
+        if NP == 2:
+            B_.cur_lane = 1
+            self._stem_bwd(pl, 1, stem_recs[1], d_xf)
+            B_.sync(0, 1)                               # join before the optimiser
         if self.wgrad_lanes:
             B_.sync(0, 2)
-            B_.sync(0, 3)
+            if NP == 2:
+                B_.sync(0, 3)
         B_.cur_lane = 0
         # bind the filter-gradient ops to their lane's scratch now that its size is known
         for oplist, slot, wp, lane in self._wg_pending:
@@ -791,7 +802,8 @@ class Engine:
             self._plans[key] = pl
         elif pl.bound != ptrs():
             self._stem_ops(pl, 0, x_slow, slow_t_index)
-            self._stem_ops(pl, 1, x_fast, None)
+            if x_fast is not None:
+                self._stem_ops(pl, 1, x_fast, None)
             pl.bound = ptrs()
             pl.inputs = (x_slow, x_fast, slow_t_index)
             pl.graph_epoch += 1                          # a captured hipGraph of this plan is stale now
@@ -841,8 +853,12 @@ class Engine:
     def forward(self, x_slow: torch.Tensor, x_fast: torch.Tensor, train: bool, slow_t_index=None) -> Plan:
         """x_*: (N, C, T, H, W) views with ANY strides (the dataset's N,T,C,H,W memory is read in place).
         If slow_t_index is given, the slow pathway reads frames x_slow[:, :, slow_t_index] (PackPathway)."""
-        assert x_slow.dim() == 5 and x_fast.dim() == 5 and x_slow.shape[0] == x_fast.shape[0]
-        assert x_slow.shape[1] == self.spec.input_channels[0] and x_fast.shape[1] == self.spec.input_channels[1]
+        assert x_slow.dim() == 5 and x_slow.shape[1] == self.spec.input_channels[0]
+        if self.spec.pathways == 2:
+            assert x_fast.dim() == 5 and x_slow.shape[0] == x_fast.shape[0]
+            assert x_fast.shape[1] == self.spec.input_channels[1]
+        else:
+            assert x_fast is None, "single-pathway network: forward(x, None, ...)"
         pl = self._plan_for(x_slow, x_fast, slow_t_index, train)
         if train:
             self.drop_seed.add_(1)

@@ -42,8 +42,12 @@ class SlowFast(torch.nn.Module):
         self.engine = Engine(spec, dtype=dtype, device=device, backend=backend, seed=seed)
         self.arena = self.engine.P          # the one trainable tensor: all live parameters, kernel layout
 
-    def forward(self, x: Sequence[torch.Tensor], slow_t_index: Optional[torch.Tensor] = None) -> torch.Tensor:
-        x_slow, x_fast = x[0], x[1]
+    def forward(self, x, slow_t_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [x_slow, x_fast] (SlowFast) or one (N,C,T,H,W) tensor (the single-pathway res3d network)."""
+        if self.spec.pathways == 1:
+            x_slow, x_fast = (x if torch.is_tensor(x) else x[0]), None
+        else:
+            x_slow, x_fast = x[0], x[1]
         if self.training and torch.is_grad_enabled():
             return _SlowFastFn.apply(self.arena, self.engine, x_slow, x_fast, slow_t_index)
         with torch.no_grad():
@@ -76,6 +80,14 @@ def init_my_slowfast(cfg, input_channels, stem_dim_outs, device="cuda", backend=
 
 def slowfast_r50_8x8(num_class: int = 400, dtype=torch.bfloat16, device="cuda", backend=None, seed: int = 0) -> SlowFast:
     return SlowFast(arch.canonical_spec(num_class), dtype=dtype, device=device, backend=backend, seed=seed)
+
+
+def slow_r50(num_class: int = 400, input_channels: int = 5, dtype=torch.float32, device="cuda", backend=None,
+             seed: int = 0, depth: int = 50, head_pool_kernel=(8, 7, 7)) -> SlowFast:
+    """The reference's `res3d` model (hub slow_r50 + 5-channel (1,7,7) stem, (deprecated)/train_3dresnet.py:47-51):
+    the same engine with one pathway; ``model(x)`` takes the (N,C,T,H,W) tensor itself."""
+    spec = arch.slow_r50_spec(num_class, input_channels, depth, tuple(head_pool_kernel))
+    return SlowFast(spec, dtype=dtype, device=device, backend=backend, seed=seed)
 
 
 def pack_pathway_index(num_frames: int, alpha: int = 4, device="cuda") -> torch.Tensor:

@@ -111,9 +111,9 @@ class TrainStep:
 
 
 class ModelManager:
-    """Name -> (init_model, prepare_data), as reference train.py:39-60.  Only the SlowFast path is accelerated;
-    'res2d' / 'res3d' are outside this engine's scope and raise like the reference does for
-    unknown names."""
+    """Name -> (init_model, prepare_data), as reference train.py:39-60.  'slowfast*' and 'res3d' (SURVEY.md section
+    8f-4: hub slow_r50 with a 5-channel stem, train.py:79-89 / (deprecated)/train_3dresnet.py:47-51) run on this
+    engine; 'res2d' (a torchvision 2-D ResNet from torch.hub, train.py:64-76) is not a video path and raises."""
 
     def __init__(self, cfg, device="cuda", backend=None):
         self.cfg, self.device, self.backend = cfg, device, backend
@@ -122,6 +122,9 @@ class ModelManager:
         if "slowfast" in name:
             self.init_model = self._init_slowfast_model
             self.prepare_data = self._prepare_slowfast_data
+        elif name == "res3d":
+            self.init_model = self._init_res3d_model
+            self.prepare_data = self._prepare_res3d_data
         else:
             raise NotImplementedError(f"MODEL.NAME={name!r}: only the SlowFast path runs on this engine")
 
@@ -146,6 +149,24 @@ class ModelManager:
         else:
             print(f'warning: {ckpt} not found, training from the reference init scheme')
         return model
+
+    def _init_res3d_model(self):
+        """slow_r50 (400 Kinetics classes, as the hub model the reference loads) with Conv3d(5, 64, (1,7,7)) as stem;
+        no pretrained file exists offline, so the reference init scheme is used."""
+        from .slowfast import _DTYPES, slow_r50
+        dtype = _DTYPES[str(self.cfg.MODEL.get("DTYPE", "fp32")).lower()]
+        t = int(self.cfg.CHALEARN.CLIP_LEN)
+        s = crop_resize_dict[self.cfg.MODEL.R3D_INPUT] // 32
+        # hub head pool (8,7,7) fits 8x224^2 clips; other geometries pool the whole res5 map they produce
+        pool = (8, 7, 7) if (t >= 8 and s >= 7) else (min(t, 8), s, s)
+        return slow_r50(400, 5, dtype=dtype, device=self.device, backend=self.backend, head_pool_kernel=pool)
+
+    def _prepare_res3d_data(self, batch):
+        """(N,T,21,S,S) -> BGR+UV (N,5,T,S,S) strided view (train.py:85-89; 5 channels as train.py:72 / the 5-channel
+        stem of :81)."""
+        x = batch[self.cfg.MODEL.R3D_INPUT].to(self.device, non_blocking=True)
+        x = torch.permute(x, [0, 2, 1, 3, 4])
+        return x[:, 0:5], batch['label'].to(self.device, non_blocking=True)
 
     def _prepare_slowfast_data(self, batch):
         """(N,T,21,S,S) -> [BGR+UV (N,5,T,S,S), flow (N,15,T,S,S)] strided views of the SAME memory; the depth channel
@@ -265,7 +286,10 @@ class Trainer:
         self.model.train()
         for batch in self.train_loader:
             x, y_true = self.mm.prepare_data(batch)
-            self.step(x[0], x[1], y_true)
+            if torch.is_tensor(x):                       # res3d: one pathway
+                self.step(x, None, y_true)
+            else:
+                self.step(x[0], x[1], y_true)
             self.num_step += 1
             seen += int(y_true.shape[0])
             if self.debug:
