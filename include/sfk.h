@@ -109,11 +109,17 @@ typedef struct {
   int32_t accumulate;
   float* stats;
   sfk_bn_bwd_fuse bnb;
+  /* optional: Y is the gradient w.r.t. a ReLU output whose mask sfk_bn_apply left as a bitmap (relu_bits: byte
+   * [pixel][co / V]); the pass then stores  result * mask  (after the += of `accumulate`), i.e. dz instead of dA, so the
+   * BatchNorm backward of that unit neither re-applies the mask nor rewrites the tensor.  The pass must cover every
+   * pixel of y in row order (os = 1, oo = 0, row extents = y extents); supported when sfk_conv_relu_out_supported(d). */
+  const uint8_t* out_relu_bits;
 } sfk_conv_desc;
 
 int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream);
 int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats / d->bnb.partials; <0 on error */
 int sfk_conv_bnb_supported(const sfk_conv_desc* d);  /* 1 if d (ignoring d->bnb) can run with the bnb fusion, else 0 */
+int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out_relu_bits) can apply a bitmap, else 0 */
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_conv_wgrad -- Conv3d filter gradient (autograd of the same nn.Conv3d modules, train.py:230).

@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
-_STAGE_DEPTHS = {18: (1, 1, 1, 1), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+_STAGE_DEPTHS = {18: (1, 1, 1, 1), 26: (2, 2, 2, 2), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
 
 def _half(k: Sequence[int]) -> Tuple[int, ...]:

@@ -77,10 +77,13 @@ class EmuBackend:
             Y = p.y.view5()
             sl = tuple(slice(o, o + (r - 1) * s + 1, s) for o, s, r in zip(p.oo, p.os, p.rows))
             dest = Y[:, sl[0], sl[1], sl[2]]
-            if p.accumulate:
-                dest.copy_((dest.float() + acc).to(Y.dtype))
-            else:
-                dest.copy_(acc.to(Y.dtype))
+            res = dest.float() + acc if p.accumulate else acc
+            if p.relu_out_bits is not None:       # Y is the gradient w.r.t. a ReLU output: store result * mask
+                vec = 8 if Y.dtype == torch.bfloat16 else 4
+                b = p.relu_out_bits[: p.y.pixels * (p.cout // vec)].to(torch.int32).reshape(-1, p.cout // vec, 1)
+                m = ((b >> torch.arange(vec, dtype=torch.int32, device=b.device)) & 1).reshape(res.shape)
+                res = res * m.float()
+            dest.copy_(res.to(Y.dtype))
             if p.stats is not None:
                 flat = acc.reshape(-1, p.cout)
                 bm = _tile_bm(p.cout)
@@ -97,6 +100,9 @@ class EmuBackend:
 
     def conv_bnb_supported(self, p) -> bool:
         return False          # the emulation keeps the stand-alone BatchNorm-backward reduce
+
+    def conv_relu_out_supported(self, p) -> bool:
+        return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
 
     def conv_wgrad(self, p: WgradPass):
         def run(stream):

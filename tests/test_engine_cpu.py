@@ -30,14 +30,16 @@ def randomize(model, seed):
                 v.copy_(torch.randn(v.shape, generator=g) * 0.05)
 
 
-def make_models(ref_style, num_class=7, dtype=torch.float32, device="cpu", backend=None):
+def make_models(ref_style, num_class=7, dtype=torch.float32, device="cpu", backend=None, depth=18):
+    """depth 18 = one (projection) block per stage; depth 26 = two: adds the identity-shortcut blocks, whose output
+    gradient is accumulated in place and masked by the pass that finishes it (sfk_conv_desc.out_relu_bits)"""
     torch.manual_seed(1234)   # the oracle's conv init draws from the global RNG
     if ref_style:
-        spec = arch.ref_spec(num_class=num_class, depth=18, head_pool_kernels=((2, 2, 2), (2, 2, 2)))
-        om = o.mini_slowfast(num_class, ref_style=True)
+        spec = arch.ref_spec(num_class=num_class, depth=depth, head_pool_kernels=((2, 2, 2), (2, 2, 2)))
+        om = o.mini_slowfast(num_class, ref_style=True, depth=depth)
     else:
-        spec = arch.canonical_spec(num_class=num_class, depth=18, head_pool_kernels=((2, 2, 2), (8, 2, 2)))
-        om = o.mini_slowfast(num_class, ref_style=False)
+        spec = arch.canonical_spec(num_class=num_class, depth=depth, head_pool_kernels=((2, 2, 2), (8, 2, 2)))
+        om = o.mini_slowfast(num_class, ref_style=False, depth=depth)
     randomize(om, 3)
     m = SlowFast(spec, dtype=dtype, device=device, backend=backend if backend is not None else EmuBackend())
     m.load_state_dict(om.state_dict(), strict=True)
@@ -146,9 +148,12 @@ def test_eval_forward_matches_oracle(ref_style):
     assert rel_err(got, want) < 1e-4
 
 
-@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
-def test_train_step_matches_oracle(ref_style):
-    om, m = make_models(ref_style)
+@pytest.mark.parametrize("ref_style,depth", [(True, 18), (False, 18), (True, 26), (False, 26)],
+                         ids=["ref", "canonical", "ref-d26", "canonical-d26"])
+def test_train_step_matches_oracle(ref_style, depth):
+    om, m = make_models(ref_style, depth=depth)
+    if depth == 26:   # block-final BN gammas are zero-initialised and randomize() redraws them; identity blocks are live
+        assert any(b.branch1 is None for st in m.engine.wiring.stages for pw in st for b in pw)
     x = make_inputs(ref_style)
     m.train()
     eng = m.engine

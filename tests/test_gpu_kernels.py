@@ -556,3 +556,57 @@ def test_conv_fused_bn_backward_reduce(hip, case):
     small = ConvPass(xg, FMap(torch.zeros(n * od[0] * od[1] * od[2] * 16, dtype=dtype, device=DEV), n, *od, 16), sp.rows, sp.gs,
                      sp.os, sp.oo, list(sp.taps), wgt[: 16 * g.wtaps * cin], g.wtaps, cin, 16)
     assert not hip.conv_bnb_supported(small)
+
+
+RELU_OUT_CASES = [
+    # cin, cout, kernel, pad, (n, t, h, w), accumulate, dtype
+    (64, 256, (1, 1, 1), (0, 0, 0), (2, 4, 24, 28), True, torch.bfloat16),      # identity-shortcut dgrad, 256x128 DMA tile
+    (256, 1024, (3, 1, 1), (1, 0, 0), (2, 4, 14, 14), True, torch.bfloat16),    # res4 conv_a dgrad shape
+    (8, 32, (3, 1, 1), (1, 0, 0), (2, 6, 9, 11), True, torch.bfloat16),         # fast pathway: 256x32 tile, ragged M
+    (16, 64, (3, 1, 1), (1, 0, 0), (1, 5, 13, 10), False, torch.bfloat16),      # 256x64 tile, plain store
+    (16, 40, (1, 1, 1), (0, 0, 0), (2, 3, 7, 9), True, torch.float32),          # parity precision: 4-channel nibbles
+]
+
+
+@pytest.mark.parametrize("case", RELU_OUT_CASES, ids=[f"c{c[0]}-{c[1]}-acc{int(c[5])}-{'bf16' if c[6] == torch.bfloat16 else 'f32'}"
+                                                      for c in RELU_OUT_CASES])
+def test_conv_output_relu_bitmap(hip, case):
+    """sfk_conv_desc.out_relu_bits: the pass stores (old +) result where the bitmap bit is set and 0 elsewhere ==
+    the plain pass followed by the mask, bit for bit; pad channels of a wider pixel record stay untouched."""
+    cin, cout, k, p, (n, t, h, w), accumulate, dtype = case
+    gen = torch.Generator().manual_seed(7 + cin + cout)
+    g = ConvGeom(cin, cout, k, (1, 1, 1), p)
+    sp = fwd_pass(g, (t, h, w))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen)
+    wgt = mk((cout * g.wtaps * cin,), dtype, gen, (g.wtaps * cin) ** -0.5)
+    px = n * t * h * w
+    base = mk((px * (cout + 8),), dtype, gen)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    keep = torch.rand(px, cout, generator=gen) > 0.45
+    packed = (keep.reshape(px, cout // vec, vec).to(torch.int32) << torch.arange(vec, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    if vec == 4:
+        packed |= 0xA0                                                  # the high nibble of an f32 byte is ignored
+    bits = packed.reshape(-1)
+
+    def out(dev):
+        return FMap(base.clone().to(dev), n, t, h, w, cout, cout + 8, 0)
+    ya, yb, yc = out(DEV), out(DEV), out("cpu")
+    plain = ConvPass(xg, ya, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt.to(DEV), g.wtaps, cin, cout, accumulate=accumulate)
+    assert hip.conv_relu_out_supported(plain)
+    hip.conv_igemm(plain)(stream())
+    masked = ConvPass(xg, yb, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt.to(DEV), g.wtaps, cin, cout, accumulate=accumulate,
+                      relu_out_bits=bits.to(DEV))
+    hip.conv_igemm(masked)(stream())
+    torch.cuda.synchronize()
+    want = ya.buf.cpu().view(px, cout + 8).clone()
+    want[:, :cout] = torch.where(keep, want[:, :cout], torch.zeros((), dtype=dtype))
+    got = yb.buf.cpu().view(px, cout + 8)
+    assert torch.equal(got.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                       want.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+    # and the restated contract (emu) agrees with the kernel
+    EmuBackend().conv_igemm(ConvPass(xc, yc, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt, g.wtaps, cin, cout,
+                                     accumulate=accumulate, relu_out_bits=bits))(0)
+    assert rel_err(got[:, :cout].float(), yc.buf.view(px, cout + 8)[:, :cout].float()) < TOL[dtype]
+    # a strided (scattering) pass cannot take a bitmap and says so
+    sc = ConvPass(xg, ya, (t, (h + 1) // 2, (w + 1) // 2), (1, 1, 1), (1, 2, 2), (0, 0, 0), list(sp.taps), wgt.to(DEV), g.wtaps, cin, cout)
+    assert not hip.conv_relu_out_supported(sc)

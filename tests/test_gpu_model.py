@@ -38,9 +38,11 @@ def test_mini_eval_forward_fp32(ref_style):
     assert rel_err(got, want) < 5e-5          # what exact-fp32 MFMA actually delivers
 
 
-@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
-def test_mini_train_step_fp32(ref_style):
-    om, m = make_models(ref_style, device=DEV, backend=hip_backend())
+@pytest.mark.parametrize("ref_style,depth", [(True, 18), (False, 18), (True, 26), (False, 26)],
+                         ids=["ref", "canonical", "ref-d26", "canonical-d26"])
+def test_mini_train_step_fp32(ref_style, depth):
+    # depth 26 adds identity-shortcut blocks: in-place gradient accumulation + the output ReLU bitmap of the dgrad pass
+    om, m = make_models(ref_style, device=DEV, backend=hip_backend(), depth=depth)
     x = make_inputs(ref_style)
     m.train()
     eng = m.engine
@@ -56,7 +58,10 @@ def test_mini_train_step_fp32(ref_style):
         if p.grad is None:
             continue
         e = rel_l2(gsd[k].cpu(), p.grad)
-        assert e < grad_tolerance(noise, k), (k, e)
+        # twice the blocks = twice the ReLU / arg-max decisions that a 1e-5 forward difference can flip: the depth-26 errors
+        # are 1e-2 .. 6e-2 on a few narrow fast-pathway tensors, different ones per input seed (tools/probe/d26_errors.py);
+        # a wiring error is O(1)
+        assert e < grad_tolerance(noise, k, floor=3e-2 if depth == 18 else 8e-2), (k, e)
     osd = om.state_dict()
     for L in eng.layers:
         assert rel_err(L.rm.cpu(), osd[L.cb.norm_key + ".running_mean"]) < 1e-4
@@ -199,7 +204,7 @@ def test_benchmark_geometry_properties_bf16():
     assert abs(losses[0] - np.log(400)) < 1.0, losses               # random init: close to ln(400)
 
 
-@pytest.mark.parametrize("variant", ["fused_bn_bwd", "deterministic_wgrad", "one_stream"])
+@pytest.mark.parametrize("variant", ["fused_bn_bwd", "deterministic_wgrad", "one_stream", "no_relu_bitmaps"])
 def test_schedule_variants_agree_bf16(variant):
     """The opt-in engine variants compute the SAME training step as the default schedule (bf16, canonical 8x8 model): the BatchNorm-backward reduce fused into the dgrad epilogues, the atomics-free filter-gradient
     workspace (bit-reproducible between two runs), and everything on one stream instead of four lanes.  Metric clip size,
@@ -228,6 +233,9 @@ def test_schedule_variants_agree_bf16(variant):
         conv = slice(0, SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, backend=hip_backend()).engine.conv_total)
         # the stems still flush with atomics; every other conv's filter gradient repeats bit for bit
         assert float((g[conv] != g2[conv]).float().mean()) < 0.02
+    elif variant == "no_relu_bitmaps":
+        # block-output ReLU masks re-read from the activation, applied by the stand-alone reduce (no out_relu_bits pass)
+        loss, g = run(relu_bits=False, relu_out_mask=False)
     else:
         loss, g = run(two_streams=False)
     assert loss == base_loss                                           # the forward is the same schedule in every variant

@@ -100,6 +100,7 @@ class ConvPass:
     accumulate: bool = False
     stats: Optional[torch.Tensor] = None  # fp32 [mtiles][cout][2]
     bnb: Optional[BnBwdFuse] = None
+    relu_out_bits: Optional[torch.Tensor] = None   # uint8 bitmap of bn_apply: the pass stores result * mask
 
 
 @dataclass
@@ -161,7 +162,8 @@ class _ConvDesc(C.Structure):
     _fields_ = [("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
                 ("gs", C.c_int32 * 3), ("os", C.c_int32 * 3), ("oo", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("w", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("bnb", _BnBwdFuse)]
+                ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("bnb", _BnBwdFuse),
+                ("out_relu_bits", C.c_void_p)]
 
 
 class _WgradDesc(C.Structure):
@@ -193,6 +195,7 @@ SIGNATURES = {
     "sfk_conv_igemm": [C.POINTER(_ConvDesc), _PV],
     "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
     "sfk_conv_bnb_supported": [C.POINTER(_ConvDesc)],
+    "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
@@ -296,6 +299,10 @@ def _c_conv(p: ConvPass) -> _ConvDesc:
         d.bnb.scale, d.bnb.shift = _ptr(b.scale), _ptr(b.shift)
         d.bnb.relu = 1 if b.relu else 0
         d.bnb.partials = _ptr(b.partials)
+    if p.relu_out_bits is not None:
+        vec = 8 if p.y.dtype == torch.bfloat16 else 4
+        assert p.relu_out_bits.dtype == torch.uint8 and p.relu_out_bits.numel() >= p.y.pixels * (p.cout // vec)
+        d.out_relu_bits = p.relu_out_bits.data_ptr()
     return d
 
 
@@ -319,6 +326,11 @@ class HipBackend:
     def conv_bnb_supported(self, p: ConvPass) -> bool:
         """can this pass take a BnBwdFuse (sfk_conv_bnb_supported)?"""
         return bool(self.lib.sfk_conv_bnb_supported(C.byref(_c_conv(p))))
+
+    def conv_relu_out_supported(self, p: ConvPass) -> bool:
+        """can this pass apply a ReLU bitmap to what it stores (sfk_conv_relu_out_supported)?"""
+        q = ConvPass(**{**p.__dict__, "relu_out_bits": None})
+        return bool(self.lib.sfk_conv_relu_out_supported(C.byref(_c_conv(q))))
 
     def conv_igemm(self, p: ConvPass):
         d, fn, keep = _c_conv(p), self.lib.sfk_conv_igemm, p

@@ -19,7 +19,7 @@ from typing import List, Optional, Tuple
 from .plan import ConvGeom
 
 Triple = Tuple[int, int, int]
-STAGE_DEPTHS = {18: (1, 1, 1, 1), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+STAGE_DEPTHS = {18: (1, 1, 1, 1), 26: (2, 2, 2, 2), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
 
 @dataclass(frozen=True)

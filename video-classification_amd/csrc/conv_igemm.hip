@@ -36,6 +36,7 @@ struct ConvK {
   int bn_yld, bn_yoff, bn_mld, bn_moff, bn_relu;
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_parts;         // [mtiles][cout][2] = (sum dz, sum dz * x_hat) per row tile; NULL = fusion off
+  const uint8_t* obits;    // ReLU bitmap applied to the stored result (sfk_conv_desc.out_relu_bits), or NULL
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
@@ -80,15 +81,20 @@ template <> struct Tile<float> {
   }
 };
 
-__device__ __forceinline__ void store4(float* p, const f32x4& v, bool acc) {
+// mbits: ReLU bitmap of the 4 channels (bit e = keep channel e), or -1 (no mask)
+__device__ __forceinline__ void store4(float* p, const f32x4& v, bool acc, int mbits = -1) {
   float4 o = make_float4(v[0], v[1], v[2], v[3]);
   if (acc) {
     const float4 old = *reinterpret_cast<const float4*>(p);
     o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
   }
+  if (mbits >= 0) {
+    o.x = (mbits & 1) ? o.x : 0.f; o.y = (mbits & 2) ? o.y : 0.f;
+    o.z = (mbits & 4) ? o.z : 0.f; o.w = (mbits & 8) ? o.w : 0.f;
+  }
   *reinterpret_cast<float4*>(p) = o;
 }
-__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, bool acc) {
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, bool acc, int = -1) {   // (bitmaps: wide stores only)
   float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
   if (acc) {
     const bf16x4 old = *reinterpret_cast<const bf16x4*>(p);
@@ -111,7 +117,7 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 __device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, f32x4 a, f32x4 b, int g, bool acc,
-                                            const bf16x8& old) {
+                                            const bf16x8& old, int mbits = -1) {
   float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
   for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
@@ -121,6 +127,10 @@ __device__ __forceinline__ void store8_pair(bf16_t* pix, int co_base, int cout, 
   if (acc) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+  }
+  if (mbits >= 0) {   // the stored tensor is a gradient w.r.t. a ReLU output: keep it where the activation was positive
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((mbits >> e) & 1) ? v[e] : 0.f;
   }
   bf16x8 o;
 #pragma unroll
@@ -138,7 +148,7 @@ __device__ __forceinline__ bf16x8 load8_old(const bf16_t* pix, int co_base, int 
   return co < cout ? *reinterpret_cast<const bf16x8*>(pix + co) : z;
 }
 __device__ __forceinline__ bf16x8 load8_old(const float*, int, int, int) { return bf16x8{}; }
-__device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool, const bf16x8&) {}   // f32 stores are 16 B already
+__device__ __forceinline__ void store8_pair(float*, int, int, f32x4, f32x4, int, bool, const bf16x8&, int = -1) {}   // f32 stores are 16 B already
 
 // 16-lane row sum with DPP shifts (4 VALU ops; __shfl_xor goes through ds_bpermute): the total ends in lane 15 of the row
 __device__ __forceinline__ float row16_sum(float v) {
@@ -254,7 +264,9 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, bool BNB = false>
+// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb), 2 output ReLU bitmap (out_relu_bits) -- own
+// instantiations: the extra epilogue state must not cost the plain kernel registers (the 256x128 tile sits at 128 VGPRs)
+template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, int EPI = 0>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
   using TL = Tile<T>;
   constexpr int VEC = TL::VEC, SEGS = TL::SEGS, ROWB = TL::ROWB;
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
 
   // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
-  if constexpr (BNB && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: its own instantiation
+  if constexpr (EPI == 1 && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: its own instantiation
     __syncthreads();        // the partial sums go through LDS that aliases the ring
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
@@ -473,6 +485,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
       }
     }
   }
+  // ReLU bitmap of the output (lin_out only: the pixel index is the row): byte [pixel][co / VEC], fetched with the old
+  // values, before the first store
+  static_assert(EPI != 2 || FN <= 8, "one packed bitmap word per fragment row");
+  uint32_t mb[EPI == 2 ? FM : 1];            // byte i/2 = the bitmap byte of this lane's store i (packed: registers)
+  bool masked = false;
+  if constexpr (EPI == 2) {
+    masked = wide && k.obits;
+    if (masked) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+        mb[j] = 0;
+        if (m < k.M) {
+#pragma unroll
+          for (int i = 0; i < FN; i += 2) {
+            const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+            if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
@@ -481,12 +515,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
       if (wide) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2]);
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2],
+                      (EPI == 2 && masked) ? (int)((mb[EPI == 2 ? j : 0] >> (8 * (i / 2))) & 255u) : -1);
       } else {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
           const int co = co_w + 16 * i + 4 * g;
-          if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+          if (co < k.cout) {
+            int mbits = -1;
+            if constexpr (EPI == 2 && sizeof(T) == 4) {
+              if (k.obits) mbits = k.obits[(int64_t)m * (k.cout >> 2) + (co >> 2)] & 15;
+            }
+            store4(yp + poff + co, acc[i][j], k.accumulate != 0, mbits);
+          }
         }
       }
     }
@@ -547,7 +588,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 //     s_barrier per K-step (never a full drain).
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int BM, int BN, int WM, int WN, bool BNB = false>
+template <int BM, int BN, int WM, int WN, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
@@ -741,7 +782,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   __syncthreads();
 
   // ---- epilogue (identical to the register-staged kernel)
-  if constexpr (BNB) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
+  if constexpr (EPI == 1) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
@@ -774,6 +815,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
       }
     }
   }
+  // ReLU bitmap of the output (lin_out only: the pixel index is the row): byte [pixel][co / VEC], fetched with the old
+  // values, before the first store
+  static_assert(EPI != 2 || FN <= 8, "one packed bitmap word per fragment row");
+  uint32_t mb[EPI == 2 ? FM : 1];            // byte i/2 = the bitmap byte of this lane's store i (packed: registers)
+  bool masked = false;
+  if constexpr (EPI == 2) {
+    masked = wide && k.obits;
+    if (masked) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+        mb[j] = 0;
+        if (m < k.M) {
+#pragma unroll
+          for (int i = 0; i < FN; i += 2) {
+            const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+            if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
@@ -782,12 +845,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
       if (wide) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2]);
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2],
+                      (EPI == 2 && masked) ? (int)((mb[EPI == 2 ? j : 0] >> (8 * (i / 2))) & 255u) : -1);
       } else {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
           const int co = co_w + 16 * i + 4 * g;
-          if (co < k.cout) store4(yp + poff + co, acc[i][j], k.accumulate != 0);
+          if (co < k.cout) {
+            int mbits = -1;
+            if constexpr (EPI == 2 && sizeof(T) == 4) {
+              if (k.obits) mbits = k.obits[(int64_t)m * (k.cout >> 2) + (co >> 2)] & 15;
+            }
+            store4(yp + poff + co, acc[i][j], k.accumulate != 0, mbits);
+          }
         }
       }
     }
@@ -850,6 +920,17 @@ inline bool bnb_ok(const sfk_conv_desc* d) {
          (((uintptr_t)d->y.ptr) & 15) == 0;
 }
 
+// out_relu_bits: the pass must write every pixel of y in row order (the bitmap is indexed by the row), and bf16 needs
+// the 16-byte store path (one bitmap byte per store)
+inline bool lin_out_of(const sfk_conv_desc* d) {
+  return d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
+         d->rt == d->y.t && d->rh == d->y.h && d->rw == d->y.w;
+}
+inline bool relu_out_ok(const sfk_conv_desc* d) {
+  if (!lin_out_of(d)) return false;
+  return d->x.dtype == SFK_F32 ? true : bnb_ok(d);
+}
+
 int validate(const sfk_conv_desc* d) {
   if (!d || !d->w) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
@@ -869,6 +950,10 @@ int validate(const sfk_conv_desc* d) {
   if (!sfk_fmap_vec_ok(&d->x)) return SFK_ERR_UNSUPPORTED;
   if ((d->y.c % 4) || (d->y.ld % 4) || (d->y.c_off % 4) || (((uintptr_t)d->y.ptr) & 15)) return SFK_ERR_UNSUPPORTED;
   if (((uintptr_t)d->w) & 15) return SFK_ERR_UNSUPPORTED;
+  if (d->out_relu_bits) {
+    if (d->bnb.partials) return SFK_ERR_INVALID;
+    if (!relu_out_ok(d)) return SFK_ERR_UNSUPPORTED;
+  }
   if (d->bnb.partials) {
     const sfk_bn_bwd_fuse& b = d->bnb;
     if (d->stats || !sfk_fmap_ok(&b.y_bn) || !b.mean || !b.invstd) return SFK_ERR_INVALID;
@@ -892,8 +977,14 @@ int validate(const sfk_conv_desc* d) {
 
 int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
   if (k.bn_parts) {
-    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, true>), grid, dim3(512), 0, s, k);
-    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, s, k);
+    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 1>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
+  if (k.obits) {
+    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 2>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
@@ -920,6 +1011,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.dkct.set(d->cin / 32 > 0 ? d->cin / 32 : 1);
   k.KC = (d->ntaps * (d->cin / vec) + segs - 1) / segs;
   k.accumulate = d->accumulate;
+  k.obits = d->out_relu_bits;
   k.bn_parts = d->bnb.partials;
   if (k.bn_parts) {
     k.bn_y = d->bnb.y_bn.ptr; k.bn_yld = d->bnb.y_bn.ld; k.bn_yoff = d->bnb.y_bn.c_off;
@@ -929,10 +1021,9 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   }
   static const int kshort = getenv("SFK_KSHORT") ? atoi(getenv("SFK_KSHORT")) : 5;   // A/B knob
   k.kshort = kshort;
-  k.lin_out = d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
-              d->rt == d->y.t && d->rh == d->y.h && d->rw == d->y.w;
+  k.lin_out = lin_out_of(d);
   static const int wide_ok = getenv("SFK_WIDE") ? atoi(getenv("SFK_WIDE")) : 1;   // A/B knob
-  k.wide_store = wide_ok && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0;
+  k.wide_store = (wide_ok || k.obits) && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
@@ -947,13 +1038,22 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   }
   if (k.bn_parts) {          // fused BatchNorm-backward reduce (bf16, cout > 16: tiles of 32..128 output channels)
     if constexpr (sizeof(T) == 2) {
-      if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, true>), grid, block, 0, s, k);
-      else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, true>), grid, block, 0, s, k);
-      else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, true>), grid, block, 0, s, k);
+      if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
+      else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 1>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 1>), grid, block, 0, s, k);
       SFK_CHECK_LAUNCH();
       return SFK_OK;
     }
     return SFK_ERR_UNSUPPORTED;
+  }
+  if (k.obits) {             // output ReLU bitmap: the look-ahead K loop also for short K (few launches, one instantiation less)
+    if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 2>), grid, block, 0, s, k);
+    else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 2>), grid, block, 0, s, k);
+    else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 2>), grid, block, 0, s, k);
+    else if (sizeof(T) == 4) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1, false, 2>), grid, block, 0, s, k);
+    else return SFK_ERR_UNSUPPORTED;
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
   }
   if (k.KC <= k.kshort && ts.bn <= 32) {   // (the wider tiles spill with the exact-count loop: 124..228 B per lane)
     if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, true>), grid, block, 0, s, k);
@@ -976,6 +1076,14 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
   const int bm = pick_tile(d->cout, d->x.dtype, M, d->ntaps * d->cin).bm;
   return (int)((M + bm - 1) / bm);
+}
+
+extern "C" int sfk_conv_relu_out_supported(const sfk_conv_desc* d) {
+  if (!d) return 0;
+  sfk_conv_desc c = *d;
+  c.out_relu_bits = nullptr;
+  if (validate(&c) != SFK_OK) return 0;
+  return relu_out_ok(d) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_bnb_supported(const sfk_conv_desc* d) {

@@ -138,6 +138,9 @@ class Engine:
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
         self.relu_bits = os.environ.get("SFK_RELU_BITS", "1") != "0"       # block-output ReLU masks kept as bitmaps
+        # ... and applied by the data-gradient pass that finishes the gradient of an identity-shortcut block's output
+        # (sfk_conv_desc.out_relu_bits): that block's BatchNorm backward then reads dz as it is, no mask, no rewrite
+        self.relu_out_mask = self.relu_bits and os.environ.get("SFK_RELU_OUT", "1") != "0"
         self.kvec = 8 if self.dtype == torch.bfloat16 else 4               # channels per 16-byte lane of the BN kernels
         # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
         # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
@@ -447,11 +450,13 @@ class Engine:
         pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
         pl.bwd.cur_lane = home
 
-    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None):
+    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None, out_bits=None):
         """data gradient of rec's conv: dy -> dx (+= when accumulate).
         fuse = (bn unit whose activation gradient dx is, mask_src | None, relu, tag): fold that unit's BatchNorm-backward
         reduce into this pass's epilogue when the backend can (single stride-1 pass, bf16, > 16 channels); returns
-        (partials, rows) then -- dx holds dz and the caller skips the reduce kernel -- else None."""
+        (partials, rows) then -- dx holds dz and the caller skips the reduce kernel -- else None.
+        out_bits: dx is the gradient w.r.t. a ReLU output whose mask is this bitmap: the pass stores result * mask when
+        the backend can (single pass over all of dx); returns "masked" then."""
         L = rec.L
         assert L.needs_dgrad
         passes, needs_zero = dgrad_passes(L.eg, (rec.x.t, rec.x.h, rec.x.w))
@@ -473,6 +478,10 @@ class Engine:
                 cp.bnb = BnBwdFuse(brec.y, mask_src, brec.mean, brec.invstd, brec.scale, brec.shift, relu, parts)
                 reduced = (parts, mt)
                 extra = float(esz * rows * L.eg.cin * (2 if mask_src is not None else 1))
+            elif out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp):
+                cp.relu_out_bits = out_bits
+                reduced = "masked"
+                extra = float(rows * L.eg.cin // self.kvec)
             pl.bwd.append(self.be.conv_igemm(cp),
                           kind="conv_dgrad", layer=L.cb.conv_key, cout=L.eg.cin,
                           flops=2.0 * rows * L.eg.cout * L.eg.cin * len(sp.taps),
@@ -590,7 +599,8 @@ class Engine:
 
     def _block_bwd(self, pl, brec, d_out: FMap, reduced_c=None, prev=None):
         """d_out: gradient w.r.t. the block output (clobbered).  returns (gradient w.r.t. the block input, reduced)
-        reduced_c: this block's final-BatchNorm reduce was already done by the pass that finished d_out (d_out holds dz);
+        reduced_c: (partials, rows) -- this block's final-BatchNorm reduce was already done by the pass that finished d_out
+        (d_out holds dz) -- or "masked": that pass applied this block's ReLU bitmap (d_out holds dz, the reduce is to do);
         prev: the record of the block that feeds this one through an identity path -- its final-BatchNorm reduce is
         folded into this block's last data-gradient pass, whose result IS the gradient of prev's output; `reduced`
         is then what to hand to prev's _block_bwd."""
@@ -598,7 +608,10 @@ class Engine:
         n = x.n
         # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
         dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
-        self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
+        if reduced_c == "masked":     # the pass that finished d_out applied this block's ReLU bitmap: d_out holds dz
+            self._bn_bwd(pl, recc, d_out, f"{tag}.c", False, None, False, dyc)
+        else:
+            self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
         self._wgrad(pl, recc, dyc)
         dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
         red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
@@ -614,7 +627,8 @@ class Engine:
             if prev is not None:
                 p_tag, p_out, p_recc = prev[1], prev[3], prev[7]
                 fuse = (p_recc, p_out, True, f"{p_tag}.c")
-            red_prev = self._dgrad(pl, reca, daa, d_out, accumulate=True, fuse=fuse)
+            p_bits = prev[8] if (prev is not None and self.relu_out_mask) else None
+            red_prev = self._dgrad(pl, reca, daa, d_out, accumulate=True, fuse=fuse, out_bits=p_bits)
             return d_out, red_prev
         dx = self._fmap(f"dx.{tag}", n, x.t, x.h, x.w, x.c)
         self._dgrad(pl, reca, daa, dx, accumulate=False)
