@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsfk.so")
+LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
 ABI_VERSION = 3        # include/sfk.h SFK_ABI_VERSION

@@ -23,6 +23,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     deps = [os.path.join(CSRC, "sfk_common.h"), os.path.join(ROOT, "include", "sfk.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    flags += os.environ.get("SFK_EXTRA_FLAGS", "").split()          # experiment builds (tools/), with SFK_LIB_OUT
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

@@ -4,7 +4,18 @@
 // in a per-block partial row that a tiny finalize kernel folds in double precision (deterministic, no atomics).
 #include "sfk_common.h"
 
+// Cache hints of the three streaming kernels: `nt` bit 0 = non-temporal stores, bit 1 = non-temporal loads, chosen per
+// launch from the map's size (nt_hint): a map far larger than the 256 MB Infinity Cache is streamed (its lines would only
+// push other lanes' working sets out), a small one stays cached -- bn_bwd_apply re-reads what bn_bwd_reduce just read.
+
 namespace {
+// thresholds in MB of ONE map (pixels * channels * element size); knobs: SFK_NT_APPLY_MB / SFK_NT_RED_MB / SFK_NT_BAPP_MB
+inline int nt_hint(const sfk_fmap* f, const char* env, int default_mb, int bits) {
+  const char* e = getenv(env);
+  const int64_t mb = e ? atoi(e) : default_mb;
+  const int64_t bytes = sfk_fmap_pixels(f) * f->c * (f->dtype == SFK_BF16 ? 2 : 4);
+  return (mb >= 0 && bytes >= (mb << 20)) ? bits : 0;
+}
 
 struct FM {  // kernel-side feature map view
   void* p;
@@ -211,10 +222,11 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // RES: 0 none, 1 plain residual, 2 residual with its own scale/shift (projection shortcut's BN)
 // relu_bits (optional, RELU only): one bit per output element, byte [pixel][channel group] = the VEC sign bits of the
 // group -- 1/16 of the bf16 map.  The backward of act(bn(y) + shortcut) reads it instead of the activation itself.
-template <typename T, int RES, bool RELU>
+template <typename T, int RES, bool RELU, int NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
                                                        const float* scale, const float* shift,
                                                        const float* rscale, const float* rshift, uint8_t* relu_bits) {
+  constexpr int nt = NT;   // compile time: a run-time choice between the two access flavours is merged into plain accesses
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
@@ -231,8 +243,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
   T* op = static_cast<T*>(out.p) + out.off + cm.cg * VEC;
   for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
     Vec16<T> v, r, o;
-    v.load(yp + p * y.ld);
-    if (RES) r.load(rp + p * res.ld);
+    if (nt & 2) {
+      v.load_nt(yp + p * y.ld);
+      if (RES) r.load_nt(rp + p * res.ld);
+    } else {
+      v.load(yp + p * y.ld);
+      if (RES) r.load(rp + p * res.ld);
+    }
     uint32_t bits = 0;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -245,18 +262,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
       }
       o.set(i, f);
     }
-    o.store(op + p * out.ld);
+    if (nt & 1) o.store_nt(op + p * out.ld);
+    else o.store(op + p * out.ld);
     if (RELU && relu_bits) relu_bits[p * cgs + cm.cg] = (uint8_t)bits;
   }
 }
 
 // ------------------------------------------------------------------ backward
 // MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0), 3 mask = relu_bits of bn_apply
-template <typename T, int MASK, bool WRITE_DZ>
+template <typename T, int MASK, bool WRITE_DZ, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc, FM dzo, int64_t pixels, int c,
                                                             const float* mean, const float* invstd,
                                                             const float* scale, const float* shift,
                                                             float* partials, const uint8_t* relu_bits) {
+  constexpr int nt = NT;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
@@ -277,8 +296,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
     T* zp = WRITE_DZ ? static_cast<T*>(dzo.p) + dzo.off + cm.cg * VEC : nullptr;
     for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
       Vec16<T> d, v, m, z;
-      d.load(dap + p * da.ld);
-      v.load(yp + p * y.ld);
+      if (nt & 2) {
+        d.load_nt(dap + p * da.ld);
+        v.load_nt(yp + p * y.ld);
+      } else {
+        d.load(dap + p * da.ld);
+        v.load(yp + p * y.ld);
+      }
       if (MASK == 2) m.load(mp + p * msrc.ld);
       uint32_t bits = 0;
       if (MASK == 3) bits = relu_bits[p * cgs + cm.cg];
@@ -293,7 +317,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
         s1[i] += dz;
         s2[i] += dz * ((yv - mu[i]) * is[i]);
       }
-      if (WRITE_DZ) z.store(zp + p * dzo.ld);
+      if (WRITE_DZ) {
+        if (nt & 1) z.store_nt(zp + p * dzo.ld);
+        else z.store(zp + p * dzo.ld);
+      }
     }
   }
   block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
@@ -315,11 +342,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
   coef[ch * 3 + 2] = (float)(s2 / count);
 }
 
-template <typename T, int MASK>
+template <typename T, int MASK, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
                                                            const float* mean, const float* invstd,
                                                            const float* scale, const float* shift,
                                                            const float* coef) {
+  constexpr int nt = NT;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
@@ -343,8 +371,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc,
   T* op = static_cast<T*>(dyo.p) + dyo.off + cm.cg * VEC;
   for (int64_t p = (int64_t)blockIdx.x * cm.rows_b + cm.row; p < pixels; p += (int64_t)gridDim.x * cm.rows_b) {
     Vec16<T> d, v, m, o;
-    d.load(dap + p * da.ld);
-    v.load(yp + p * y.ld);
+    if (nt & 2) {
+      d.load_nt(dap + p * da.ld);
+      v.load_nt(yp + p * y.ld);
+    } else {
+      d.load(dap + p * da.ld);
+      v.load(yp + p * y.ld);
+    }
     if (MASK == 2) m.load(mp + p * msrc.ld);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -354,7 +387,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc,
       if (MASK == 2) dz = (m.get(i) > 0.f) ? dz : 0.f;
       o.set(i, c0[i] * (dz - c1[i] - (yv - mu[i]) * is[i] * c2[i]));
     }
-    o.store(op + p * dyo.ld);
+    if (nt & 1) o.store_nt(op + p * dyo.ld);
+    else o.store(op + p * dyo.ld);
   }
 }
 
@@ -414,7 +448,12 @@ int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np), blk(256);
   const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
   const int mode = !res ? 0 : (rs ? 2 : 1);
-#define SFK_APPLY(R, A) hipLaunchKernelGGL((bn_apply_kernel<T, R, A>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits)
+  const int nt = nt_hint(y, "SFK_NT_APPLY_MB", 0, 3);
+#define SFK_APPLY(R, A)                                                                                                      \
+  do {                                                                                                                     \
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<T, R, A, 3>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits); \
+    else hipLaunchKernelGGL((bn_apply_kernel<T, R, A, 0>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits);    \
+  } while (0)
   if (relu) {
     if (mode == 0) SFK_APPLY(0, true); else if (mode == 1) SFK_APPLY(1, true); else SFK_APPLY(2, true);
   } else {
@@ -459,7 +498,12 @@ int launch_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms,
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, max_parts, &np), blk(256);
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), z = fm_of(dzo);
   const int mask = bits ? 3 : (ms ? 2 : (relu ? 1 : 0));
-#define SFK_RED(M, W) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits)
+  const int nt = nt_hint(y, "SFK_NT_RED_MB", 48, 2);
+#define SFK_RED(M, W)                                                                                                        \
+  do {                                                                                                                     \
+    if (nt) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 2>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits); \
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 0>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits);    \
+  } while (0)
   if (dzo) {
     if (mask == 0) SFK_RED(0, true); else if (mask == 1) SFK_RED(1, true); else if (mask == 2) SFK_RED(2, true); else SFK_RED(3, true);
   } else {
@@ -480,7 +524,12 @@ int launch_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, 
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np), blk(256);
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), o = fm_of(dy);
   const int mask = ms ? 2 : (relu ? 1 : 0);
-#define SFK_APP(M) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, invstd, scale, shift, coef)
+  const int nt = nt_hint(y, "SFK_NT_BAPP_MB", 150, 3);
+#define SFK_APP(M)                                                                                                           \
+  do {                                                                                                                     \
+    if (nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, 3>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, invstd, scale, shift, coef); \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, 0>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, invstd, scale, shift, coef);    \
+  } while (0)
   if (mask == 0) SFK_APP(0); else if (mask == 1) SFK_APP(1); else SFK_APP(2);
 #undef SFK_APP
   SFK_CHECK_LAUNCH();

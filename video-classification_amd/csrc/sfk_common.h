@@ -64,6 +64,8 @@ template <> struct Vec16<float> {
   float4 v;
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ void load_nt(const float* p) { load(p); }      // parity precision: plain accesses
+  __device__ __forceinline__ void store_nt(float* p) const { store(p); }
   __device__ __forceinline__ float get(int i) const { return reinterpret_cast<const float*>(&v)[i]; }
   __device__ __forceinline__ void set(int i, float f) { reinterpret_cast<float*>(&v)[i] = f; }
   __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -72,6 +74,9 @@ template <> struct Vec16<bf16_t> {
   bf16x8 v;
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
   __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+  // streaming variants (non-temporal hint): for tensors the kernel touches once and nobody re-reads soon
+  __device__ __forceinline__ void load_nt(const bf16_t* p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+  __device__ __forceinline__ void store_nt(bf16_t* p) const { __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p)); }
   __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
   __device__ __forceinline__ void set(int i, float f) { v[i] = (bf16_t)f; }
   __device__ __forceinline__ void zero() {
