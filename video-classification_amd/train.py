@@ -14,6 +14,7 @@ What differs from /root/reference/train.py, and why:
 from __future__ import annotations
 
 import glob
+import os
 from pathlib import Path
 from typing import Callable, List, Optional
 
@@ -48,6 +49,12 @@ class TrainStep:
         self.correct = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps = 0
         self._cache = {}
+        # The trunk (lane 0: slow pathway, head, loss, optimiser) is the longest dependency chain of the step; it runs on a
+        # HIGH-priority stream of its own so that its next kernel gets CUs ahead of the filter-gradient lanes' backlog
+        # (measured +0.8 % clips/s).  The caller's stream waits for the step as before.
+        self._trunk = None
+        if dev.type == "cuda" and not self.use_graph and os.environ.get("SFK_TRUNK_PRIO", "-1") != "0":
+            self._trunk = torch.cuda.Stream(dev, priority=-1)
 
     def reset_meters(self):
         self.loss_sum.zero_()
@@ -94,7 +101,14 @@ class TrainStep:
             self._cache[key] = ent
         ent["calls"] += 1
         if not self.use_graph:
-            self._eager(pl, ent["ops"])
+            if self._trunk is not None:
+                cur = torch.cuda.current_stream(eng.device)
+                self._trunk.wait_stream(cur)
+                with torch.cuda.stream(self._trunk):
+                    self._eager(pl, ent["ops"])
+                cur.wait_stream(self._trunk)
+            else:
+                self._eager(pl, ent["ops"])
         elif ent["graph"] is not None:
             ent["graph"].replay()
         elif ent["calls"] < 2:
