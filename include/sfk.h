@@ -112,7 +112,8 @@ typedef struct {
   /* optional: Y is the gradient w.r.t. a ReLU output whose mask sfk_bn_apply left as a bitmap (relu_bits: byte
    * [pixel][co / V]); the pass then stores  result * mask  (after the += of `accumulate`), i.e. dz instead of dA, so the
    * BatchNorm backward of that unit neither re-applies the mask nor rewrites the tensor.  The pass must cover every
-   * pixel of y in row order (os = 1, oo = 0, row extents = y extents); supported when sfk_conv_relu_out_supported(d). */
+   * pixel of y in row order (os = 1, oo = 0, row extents = y extents); 8-byte aligned; supported when
+   * sfk_conv_relu_out_supported(d). */
   const uint8_t* out_relu_bits;
 } sfk_conv_desc;
 

@@ -493,15 +493,34 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   if constexpr (EPI == 2) {
     masked = wide && k.obits;
     if (masked) {
+      // the wave's FN*16 channels of a pixel are FN*2 consecutive bitmap bytes: one aligned 4- or 8-byte load per pixel
+      // row (the 4 lanes of a pixel fetch the same word) when the channel count allows, else one byte load per store
+      const bool word = (FN == 4 || FN == 2) && (k.cout % (FN * 16)) == 0;
+      const int sh = 8 * (2 * (g & 1) + (g >> 1));          // this lane's byte within each 4-byte group
+      if (word) {
+        // branch-free (rows past M re-read the last row; nothing is stored for them): a load under a branch makes hipcc
+        // drain vmcnt after it, one serial round trip per pixel row
+        uint2 w[FM];
 #pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-        mb[j] = 0;
-        if (m < k.M) {
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          const uint8_t* bp = k.obits + (int64_t)(m < k.M ? m : k.M - 1) * (k.cout >> 3) + (co_w >> 3);
+          if constexpr (FN == 4) w[j] = *reinterpret_cast<const uint2*>(bp);
+          else w[j] = make_uint2(*reinterpret_cast<const uint32_t*>(bp), 0u);
+        }
 #pragma unroll
-          for (int i = 0; i < FN; i += 2) {
-            const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
-            if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+        for (int j = 0; j < FM; ++j) mb[j] = ((w[j].x >> sh) & 255u) | (((w[j].y >> sh) & 255u) << 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          mb[j] = 0;
+          if (m < k.M) {
+#pragma unroll
+            for (int i = 0; i < FN; i += 2) {
+              const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+              if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+            }
           }
         }
       }
@@ -823,15 +842,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   if constexpr (EPI == 2) {
     masked = wide && k.obits;
     if (masked) {
+      // the wave's FN*16 channels of a pixel are FN*2 consecutive bitmap bytes: one aligned 4- or 8-byte load per pixel
+      // row (the 4 lanes of a pixel fetch the same word) when the channel count allows, else one byte load per store
+      const bool word = (FN == 4 || FN == 2) && (k.cout % (FN * 16)) == 0;
+      const int sh = 8 * (2 * (g & 1) + (g >> 1));          // this lane's byte within each 4-byte group
+      if (word) {
+        // branch-free (rows past M re-read the last row; nothing is stored for them): a load under a branch makes hipcc
+        // drain vmcnt after it, one serial round trip per pixel row
+        uint2 w[FM];
 #pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-        mb[j] = 0;
-        if (m < k.M) {
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          const uint8_t* bp = k.obits + (int64_t)(m < k.M ? m : k.M - 1) * (k.cout >> 3) + (co_w >> 3);
+          if constexpr (FN == 4) w[j] = *reinterpret_cast<const uint2*>(bp);
+          else w[j] = make_uint2(*reinterpret_cast<const uint32_t*>(bp), 0u);
+        }
 #pragma unroll
-          for (int i = 0; i < FN; i += 2) {
-            const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
-            if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+        for (int j = 0; j < FM; ++j) mb[j] = ((w[j].x >> sh) & 255u) | (((w[j].y >> sh) & 255u) << 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          mb[j] = 0;
+          if (m < k.M) {
+#pragma unroll
+            for (int i = 0; i < FN; i += 2) {
+              const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+              if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+            }
           }
         }
       }
