@@ -79,8 +79,15 @@ __device__ __forceinline__ int64_t plane_base(const StemK& k, int pl, int n, int
 
 template <typename S>
 __device__ __forceinline__ void plane_fetch(const StemK& k, const PatchSlots& ps, int64_t base, float (&v)[NSLOT]) {
+  // branch-free: padding slots read element 0 of the plane and are zeroed by a select (a load under a branch makes
+  // hipcc drain vmcnt behind it -- NSLOT serial round trips per plane instead of one)
+  const bool bok = base >= 0;
+  const int64_t b = bok ? base : 0;
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) v[i] = (base >= 0 && ps.ok[i]) ? ldsrc<S>(k.src, base + ps.off[i]) : 0.f;
+  for (int i = 0; i < NSLOT; ++i) {
+    const float x = ldsrc<S>(k.src, b + (ps.ok[i] ? ps.off[i] : 0));
+    v[i] = (bok && ps.ok[i]) ? x : 0.f;
+  }
 }
 
 template <typename T>
@@ -176,9 +183,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemK k) {
     int pl = 0;
     for (; pl + 3 <= k.planes; pl += 3) {                     // 18 loads in flight per thread
       float v0[NSLOT], v1[NSLOT], v2[NSLOT];
-      plane_fetch<S>(k, ps, plane_base(k, pl, n, to), v0);
-      plane_fetch<S>(k, ps, plane_base(k, pl + 1, n, to), v1);
-      plane_fetch<S>(k, ps, plane_base(k, pl + 2, n, to), v2);
+      // the three frame lookups first (one wait), then all 18 element loads back to back
+      const int64_t b0 = plane_base(k, pl, n, to), b1 = plane_base(k, pl + 1, n, to), b2 = plane_base(k, pl + 2, n, to);
+      plane_fetch<S>(k, ps, b0, v0);
+      plane_fetch<S>(k, ps, b1, v1);
+      plane_fetch<S>(k, ps, b2, v2);
       plane_store<T>(patch + pl * PR * PC, v0);
       plane_store<T>(patch + (pl + 1) * PR * PC, v1);
       plane_store<T>(patch + (pl + 2) * PR * PC, v2);
@@ -313,9 +322,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemK k) {
       const int e = tid + 256 * i;
       const int p = e / DSEG, seg = e % DSEG;
       const int ho = ho0 + (p >> 4), wo = wo0 + (p & 15);
-      dv[i] = make_uint4(0, 0, 0, 0);
-      if (ho < k.ho && wo < k.wo && seg * VEC < k.cout)
-        dv[i] = *reinterpret_cast<const uint4*>(dyp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + seg * VEC);
+      // branch-free (see plane_fetch): slots outside the map read the first 16 bytes of dY and are zeroed by a select
+      const bool ok = ho < k.ho && wo < k.wo && seg * VEC < k.cout;
+      const int64_t off = ok ? ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + seg * VEC : 0;
+      const uint4 x = *reinterpret_cast<const uint4*>(dyp + off);
+      dv[i] = ok ? x : make_uint4(0, 0, 0, 0);
     }
   };
   auto stage = [&]() {
