@@ -229,6 +229,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # rank 0's instrumented step is over: every rank leaves together
         torch.distributed.destroy_process_group()
 
 
