@@ -618,6 +618,11 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
     if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s, dry);
     return launch_dma<128, 4>(k, d, s, dry);
   }
+  if constexpr (sizeof(T) == 2) {
+    // wide output, narrow input (slow res2 conv_c: 64 -> 256): ONE tile holds all of dW, so x and dY are each read once
+    static const int wide_co = getenv("SFK_WG_WIDECO") ? atoi(getenv("SFK_WG_WIDECO")) : 1;   // A/B knob
+    if (wide_co && d->cout >= 256 && cols > 32 && cols <= 64) return launch_cfg<T, 256, 64, 1>(k, d, s, dry);
+  }
   if (cols <= 32) {
     if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s, dry);
     if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s, dry);
