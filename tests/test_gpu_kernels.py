@@ -55,6 +55,9 @@ CONV_CASES = [
     (64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 64, 66)),  # M = 33792 rows: the 256x128 LDS-DMA tile, uniform-K walk
     (80, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 8, 72, 60)),  # M = 34560, cin = 2.5 K-steps: 256x128 tile, packed-K walk
     (128, 96, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 20, 22)),  # 128x128 LDS-DMA tile, 9 taps, stride 2, ragged cout
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 28, 28)),   # conv_b of slow res3 at reduced size
+    (64, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 56, 56)),  # 56-wide rows, 2 co tiles
+    (128, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 14, 14)),  # 14x14 frames, 2 ci tiles
 ]
 
 
