@@ -58,6 +58,8 @@ CONV_CASES = [
     (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 28, 28)),   # conv_b of slow res3 at reduced size
     (64, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 56, 56)),  # 56-wide rows, 2 co tiles
     (128, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 14, 14)),  # 14x14 frames, 2 ci tiles
+    (64, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 120, 160)),  # 600 row tiles: more tiles than resident workgroups (persistent kernel: several tiles per block)
+    (32, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 5, 96, 112)),  # 630 x 2 tiles, 3 taps, ragged last tile
 ]
 
 
@@ -568,6 +570,7 @@ RELU_OUT_CASES = [
     (8, 32, (3, 1, 1), (1, 0, 0), (2, 6, 9, 11), True, torch.bfloat16),         # fast pathway: 256x32 tile, ragged M
     (16, 64, (3, 1, 1), (1, 0, 0), (1, 5, 13, 10), False, torch.bfloat16),      # 256x64 tile, plain store
     (16, 40, (1, 1, 1), (0, 0, 0), (2, 3, 7, 9), True, torch.float32),          # parity precision: 4-channel nibbles
+    (64, 256, (1, 1, 1), (0, 0, 0), (2, 4, 120, 150), True, torch.bfloat16),    # 563 x 2 tiles (several per persistent block), ragged
 ]
 
 

@@ -35,12 +35,16 @@ x = FMap(torch.randn(n * dims[0] * dims[1] * dims[2] * cin, device=dev).bfloat16
 y = FMap(torch.randn(n * od[0] * od[1] * od[2] * cout, device=dev).bfloat16(), n, *od, cout)
 w = (torch.randn(cout * g.wtaps * cin, device=dev) * (g.wtaps * cin) ** -0.5).bfloat16()
 runs = []
-if op == "fwd":
+if op in ("fwd", "fwdns"):          # fwdns: without the BatchNorm partial sums
     sp = fwd_pass(g, dims)
     ps = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cin, cout)
     mt = be.conv_igemm_mtiles(ps)
-    ps.stats = torch.zeros(mt * cout * 2, device=dev)
+    if op == "fwd":
+        ps.stats = torch.zeros(mt * cout * 2, device=dev)
     runs = [be.conv_igemm(ps)]
+elif op == "dgradacc":              # data gradient accumulated into dx (identity shortcut)
+    for sp in dgrad_passes(g, dims)[0]:
+        runs.append(be.conv_igemm(ConvPass(y, x, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cout, cin, accumulate=True)))
 elif op == "dgrad":
     for sp in dgrad_passes(g, dims)[0]:
         runs.append(be.conv_igemm(ConvPass(y, x, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, g.wtaps, cout, cin)))

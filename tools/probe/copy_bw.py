@@ -14,3 +14,14 @@ for mb in (32, 128, 411, 822):
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 10
         print(f"{mb:4d} MB {name:12s} {ms*1e3:8.1f} us  {traffic * mb * 1.048576 / ms:8.1f} GB/s")
+for mb in (128, 411, 822):      # write-only
+    n = mb * (1 << 20) // 2
+    y = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3): y.fill_(1.0)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10): y.fill_(1.0)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 10
+    print(f"{mb:4d} MB fill (write) {ms*1e3:8.1f} us  {mb * 1.048576 / ms:8.1f} GB/s")
