@@ -345,8 +345,17 @@ __global__ __launch_bounds__(256) void fc_bwd_dfeat_kernel(const float* dl, cons
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * f) return;
   const int ni = idx / f, fi = idx % f;
+  // the whole backward waits for this kernel: keep 8 independent loads in flight per thread (sum order unchanged)
   float s = 0.f;
-  for (int ki = 0; ki < k; ++ki) s += dl[ni * k + ki] * w[(int64_t)ki * f + fi];
+  int ki = 0;
+  for (; ki + 8 <= k; ki += 8) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(ki + u) * f + fi];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += dl[ni * k + ki + u] * wv[u];
+  }
+  for (; ki < k; ++ki) s += dl[ni * k + ki] * w[(int64_t)ki * f + fi];
   dfeat[idx] = s;
 }
 
