@@ -457,7 +457,7 @@ class HipBackend:
         rows_b = 256 // cgs_b
         parts = (y.pixels + rows_b * 16 - 1) // (rows_b * 16)
         cchunks = (cgs + 255) // 256
-        parts = min(parts, max(1, 2048 // cchunks))
+        parts = min(parts, max(1, int(os.environ.get("SFK_BN_PARTS", "1024")) // cchunks))
         if max_parts > 0:
             parts = min(parts, max_parts)
         return max(1, parts)

@@ -52,7 +52,8 @@ inline dim3 chan_grid(int cgs, int64_t pixels, int max_parts, int* nparts) {
   const int rows_b = 256 / cgs_b;
   int64_t parts = (pixels + (int64_t)rows_b * 16 - 1) / ((int64_t)rows_b * 16);  // >= 16 pixels per thread
   const int cchunks = (cgs + 255) / 256;
-  int64_t cap = 2048 / cchunks;
+  static const int cap_all = getenv("SFK_BN_PARTS") ? atoi(getenv("SFK_BN_PARTS")) : 1024;   // A/B knob (engine.MAX_PARTS follows it)
+  int64_t cap = cap_all / cchunks;
   if (cap < 1) cap = 1;
   if (parts > cap) parts = cap;
   if (max_parts > 0 && parts > max_parts) parts = max_parts;

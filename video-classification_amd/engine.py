@@ -25,7 +25,7 @@ from ._lib import BN_FOLD_ROWS, BnBwdFuse, ConvPass, FMap, StemSrc, WgradPass, s
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
-MAX_PARTS = 2048
+MAX_PARTS = int(os.environ.get("SFK_BN_PARTS", "1024"))
 
 
 @dataclass
