@@ -41,7 +41,10 @@ struct ChanMap {
 // SFK_BN_U rows before the first use, and a block touches one contiguous stretch of memory (measured on bn_bwd_apply:
 // 5.22 ms per step with one row per iteration and a 2048-block grid-stride loop, 4.93 with 4 rows per iteration, 4.61 with
 // one span per thread and as many blocks as there are spans).
-constexpr int SFK_BN_U = 4;
+#ifndef SFK_BN_U_ROWS
+#define SFK_BN_U_ROWS 4
+#endif
+constexpr int SFK_BN_U = SFK_BN_U_ROWS;
 inline unsigned span_blocks(int cgs, int64_t pixels) {
   const int cgs_b = cgs < 256 ? cgs : 256, rows_b = 256 / cgs_b;
   const int64_t want = (pixels + (int64_t)rows_b * SFK_BN_U - 1) / ((int64_t)rows_b * SFK_BN_U);
