@@ -75,12 +75,13 @@ class RefFusionBuilder:
 
 
 def init_my_slowfast(num_class: int, input_channels: Sequence[int], stem_dim_outs: Sequence[int],
-                     fuse: bool = True) -> nn.Module:
+                     fuse: bool = True, depth: int = 50) -> nn.Module:
     """The model ``train.py:114`` trains: ``init_my_slowfast(cfg, (5, 15), (64, 8))``.
 
     Same clip length on both pathways; both stems (1,7,7)/(1,2,2) + MaxPool (1,3,3)/(1,2,2); conv_a kernels
     slow ((1,1,1),(1,1,1),(3,1,1),(3,1,1)) / fast all (3,1,1); conv_b (1,3,3); spatial strides (1,2,2,2);
-    head AvgPool (4,2,2) stride 1 on both pathways; depth 50 (my_slowfast.py:50-99)."""
+    head AvgPool (4,2,2) stride 1 on both pathways; depth 50 (my_slowfast.py:50-99; `depth` exists for the small
+    test networks only -- the reference hard-codes 50 at :98)."""
     n = len(input_channels)
     assert n >= 2 and len(stem_dim_outs) == n
     ratios = tuple(int(stem_dim_outs[0]) // int(c) for c in stem_dim_outs[1:])
@@ -94,7 +95,7 @@ def init_my_slowfast(num_class: int, input_channels: Sequence[int], stem_dim_out
     return pv.create_slowfast(
         slowfast_channel_reduction_ratio=ratios,
         slowfast_conv_channel_fusion_ratio=fusion_ratio,
-        model_depth=50,
+        model_depth=depth,
         model_num_class=num_class,
         input_channels=tuple(input_channels),
         fusion_builder=builder,

@@ -468,7 +468,7 @@ class EmuBackend:
                 k = int(torch.argmax(ps[r0:r1].sum(0) / (r1 - r0)))
                 pred[v] = k
                 if correct is not None and k == int(labels[r0]):
-                    correct += 1
+                    correct.add_(1)
         return run
 
     def sparse_fusion_fwd(self, x, w, b, y, n, p, c):

@@ -40,16 +40,26 @@ def _worker(rank, world, port, out_dir):
     labels = torch.randint(0, 5, (world * 2,), generator=g)
     idx = sdist.shard_indices(world * 2, rank, world, epoch_seed=0, shuffle=False)
     x = clips[idx].permute(0, 2, 1, 3, 4)
+    m.train()
+    # this rank's own gradient first (no exchange, lr 0), with the dropout seed and BN statistics put back afterwards
+    seed0 = eng.drop_seed.clone()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    TrainStep(eng, lr=0.0, use_graph=False)(x[:, 0:5], x[:, 5:20], labels[idx])
+    g_local = eng.G.clone()
+    eng.drop_seed.copy_(seed0)
+    m.load_state_dict(sd0)
+    eng.adam_m = eng.adam_v = eng.adam_step = None
     red = sdist.GradReducer(eng.G, bucket_mb=0.25)
     step = TrainStep(eng, lr=1e-2, use_graph=False, reducer=red, overlap_segments=4)
-    m.train()
+    assert step.world == world
     step(x[:, 0:5], x[:, 5:20], labels[idx])
     # every arena element was reduced exactly once
     cover = torch.zeros(eng.arena_numel, dtype=torch.int32)
     for off, n in red.reduced:
         cover[off:off + n] += 1
     assert int(cover.min()) == 1 and int(cover.max()) == 1
-    torch.save({"P": eng.P.data.clone(), "G": eng.G.clone(), "idx": idx}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"P": eng.P.data.clone(), "G": eng.G.clone(), "idx": idx, "g_local": g_local, "P0": sd0},
+               os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +73,8 @@ def test_two_rank_step_gloo(tmp_path):
     assert sorted(a["idx"] + b["idx"]) == [0, 1, 2, 3] and not set(a["idx"]) & set(b["idx"])
     assert torch.equal(a["G"], b["G"])          # summed gradients are identical on both ranks
     assert torch.equal(a["P"], b["P"])          # so are the updated weights
+    # ... and the exchanged gradient is the SUM of what each rank computed alone (Adam then applies 1/world)
+    assert float((a["G"] - (a["g_local"] + b["g_local"])).abs().max()) <= 1e-6 * float(a["G"].abs().max())
 
 
 def test_range_helpers():
@@ -71,3 +83,89 @@ def test_range_helpers():
     assert split_ranges([(0, 10)], 4) == [(0, 4), (4, 4), (8, 2)]
     parts = [shard_indices(10, r, 3, epoch_seed=1) for r in range(3)]
     assert all(len(p) == 3 for p in parts) and len(set(sum(parts, []))) == 9
+
+
+# ------------------------------------------------------------------ the TRAINER on two ranks (not just TrainStep)
+def _trainer_cfg(root):
+    from video_classification_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.CHALEARN.ROOT = str(root)
+    cfg.CHALEARN.BATCH_SIZE = 2
+    cfg.CHALEARN.CLIP_LEN = 4
+    cfg.CHALEARN.NUM_CLASS = 5
+    cfg.MODEL.NAME = "slowfast-LHand"
+    cfg.MODEL.R3D_INPUT = "CropLHand"
+    cfg.MODEL.DEPTH = 18
+    cfg.MODEL.LR = 1e-3
+    cfg.NUM_CPU = 0
+    return cfg
+
+
+def _trainer_sets(cfg):
+    from video_classification_amd.train import SyntheticChalearn
+
+    class Logged(SyntheticChalearn):
+        seen = None
+
+        def __getitem__(self, i):
+            self.seen.append(int(i))
+            return super().__getitem__(i)
+    tr = Logged(cfg, "train", num_videos=9, seed=1)          # 9 clips, 2 ranks: one is dropped (drop_last semantics)
+    tr.seen = []
+    te = SyntheticChalearn(cfg, "test", num_videos=5, clips_per_video=(1, 3), seed=2)
+    return tr, te
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from emu_backend import EmuBackend
+    from video_classification_amd.train import Trainer
+    cfg = _trainer_cfg(out_dir)
+    tr, te = _trainer_sets(cfg)
+    t = Trainer(cfg, train_set=tr, test_set=te, device="cpu", backend=EmuBackend(), dist_backend="gloo")
+    assert (t.rank, t.world) == (rank, world)
+    ev = t.run_eval()                                        # fresh weights: comparable with the 1-rank run of the parent
+    epochs = []
+    for e in range(2):
+        t.epoch = e
+        tr.seen = []
+        t.train_epoch()
+        epochs.append(list(tr.seen))
+    t.save_ckpt(epoch=1, acc=0.5)                            # rank 0 only
+    torch.save({"eval": ev, "epochs": epochs, "P": t.model.engine.P.data.clone(),
+                "steps": int(t.model.engine.adam_step[0])}, os.path.join(out_dir, f"trainer_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trainer_shards_epoch_and_eval_over_two_ranks(tmp_path):
+    """/root/reference/train.py:164 semantics (one shuffled epoch, drop_last) cut into disjoint per-rank shards, a new
+    permutation per epoch; run_eval sharded by video and gathered: the same dict as the 1-rank run (train.py:287-370);
+    one checkpoint, written by rank 0."""
+    world, port = 2, _free_port()
+    mp.spawn(_trainer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / "trainer_rank0.pt", weights_only=False)
+    b = torch.load(tmp_path / "trainer_rank1.pt", weights_only=False)
+    for e in range(2):
+        ia, ib = a["epochs"][e], b["epochs"][e]
+        assert len(ia) == len(ib) == 4                       # 9 // 2 clips per rank, batch 2: two steps on each rank
+        assert not set(ia) & set(ib) and len(set(ia) | set(ib)) == 8 and set(ia) | set(ib) <= set(range(9))
+    assert (a["epochs"][0], b["epochs"][0]) != (a["epochs"][1], b["epochs"][1])      # re-shuffled per epoch
+    assert a["steps"] == b["steps"] == 4 and torch.equal(a["P"], b["P"])
+    # eval: both ranks hold the full result, identical to a single process over the whole test set
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu_backend import EmuBackend
+    from video_classification_amd.train import Trainer
+    cfg = _trainer_cfg(tmp_path / "single")
+    tr, te = _trainer_sets(cfg)
+    one = Trainer(cfg, train_set=tr, test_set=te, device="cpu", backend=EmuBackend()).run_eval()
+    for r in (a["eval"], b["eval"]):
+        assert r["sv"] == one["sv"] == te.nclips and r["acc"] == one["acc"]
+        assert (r["t"] == one["t"]).all() and abs(r["ps"] - one["ps"]).max() < 1e-6
+    files = os.listdir(tmp_path / "logs" / "checkpoints" / "slowfast-LHand")
+    assert files == ["acc0.500_e1.ckpt"]

@@ -10,8 +10,9 @@ import torch
 
 from helpers import rel_err, rel_l2
 from oracle import my_slowfast as o
-from test_engine_cpu import (engine_grads_as_state_dict, grad_tolerance, make_inputs, make_models, oracle_grad_noise,
-                             oracle_train_step_with_engine_mask, randomize)
+from test_engine_cpu import (LABELS8, assert_k_step_parity, engine_grads_as_state_dict, grad_tolerance,
+                             grad_tolerance_n8, make_inputs, make_models, oracle_grad_noise,
+                             oracle_train_step_with_engine_mask, randomize, run_k_steps)
 from video_classification_amd import arch
 from video_classification_amd.slowfast import SlowFast, pack_pathway_index
 
@@ -333,3 +334,171 @@ def test_res3d_full_size_bf16_trains_through_the_trainer(tmp_path):
     assert res["ps"].shape == (n, 400) and res["sv"] == te_set.nclips and np.allclose(res["ps"].sum(1), 1.0, atol=1e-5)
     sd = trainer.model.state_dict()
     assert "blocks.5.proj.weight" in sd and tuple(sd["blocks.0.conv.weight"].shape) == (64, 5, 1, 7, 7)
+
+
+# ------------------------------------------------------------------ the fused TrainStep (what bench.py times) against the oracle
+@pytest.mark.parametrize("ref_style,depth", [(True, 18), (False, 18), (True, 26), (False, 26)],
+                         ids=["ref", "canonical", "ref-d26", "canonical-d26"])
+def test_train_step_k_steps_fp32(ref_style, depth):
+    """reference train.py:225-231 as ONE unit, three times: filter refresh -> forward -> CE -> zero_grad -> backward -> Adam
+    on the four-lane schedule, every parameter's update against oracle.my_slowfast.train_step's sequence (Adam lr 2e-4)."""
+    om, m = make_models(ref_style, device=DEV, backend=hip_backend(), depth=depth)
+    losses, upd = run_k_steps(om, m, make_inputs(ref_style), torch.tensor([1, 4]), k=3, lr=2e-4, device=DEV)
+    assert_k_step_parity(losses, upd, 2e-4, 3)
+
+
+def test_res3d_train_step_k_steps_fp32():
+    from test_engine_cpu import make_res3d, oracle_res3d_train_step, res3d_input
+    om, m = make_res3d(device=DEV, backend=hip_backend())
+    losses, upd = run_k_steps(om, m, res3d_input(), torch.tensor([2, 5]), k=3, lr=2e-4,
+                              oracle_step=oracle_res3d_train_step, device=DEV)
+    assert_k_step_parity(losses, upd, 2e-4, 3)
+
+
+@pytest.mark.parametrize("ref_style", [True, False], ids=["ref", "canonical"])
+def test_train_step_two_steps_bf16_vs_fp32_oracle(ref_style):
+    """benchmark precision: two fused steps in bf16 move the weights the way the fp32 oracle's two steps do (cosine of
+    the update per tensor; bf16 storage flips ReLU / arg-max decisions of this tiny batch, so direction, not digits)."""
+    om, m = make_models(ref_style, dtype=torch.bfloat16, device=DEV, backend=hip_backend())
+    losses, upd = run_k_steps(om, m, make_inputs(ref_style, n=8), torch.tensor(LABELS8), k=2, lr=2e-4, device=DEV)
+    for lo, lm in losses:
+        assert abs(lo - lm) < 0.1 * max(lo, 0.1), losses
+    cos = sorted(v[0] for v in upd.values())
+    assert np.median(cos) > 0.9 and cos[0] > 0.5, (cos[:5], np.median(cos))
+    assert all(0.8 < v[1] < 1.25 for v in upd.values())
+
+
+@pytest.mark.parametrize("ref_style,depth", [(True, 18), (False, 18), (True, 26), (False, 26)],
+                         ids=["ref", "canonical", "ref-d26", "canonical-d26"])
+def test_mini_train_step_gradients_batch8_fp32(ref_style, depth):
+    """the sharp whole-model gradient check: batch 8, a few percent relative L2 per tensor, no cap (grad_tolerance_n8)"""
+    om, m = make_models(ref_style, device=DEV, backend=hip_backend(), depth=depth)
+    x = make_inputs(ref_style, n=8)
+    labels = torch.tensor(LABELS8)
+    m.train()
+    eng = m.engine
+    y_o, _ = oracle_train_step_with_engine_mask(om, eng, x, labels)
+    noise = oracle_grad_noise(om, eng, x, labels)
+    y_m = m([t.to(DEV) for t in x])
+    torch.nn.functional.cross_entropy(y_m, labels.to(DEV)).backward()
+    assert rel_err(y_m.detach().cpu(), y_o) < FWD_TOL_F32
+    gsd = engine_grads_as_state_dict(eng)
+    worst = (0.0, None)
+    for k, p in om.named_parameters():
+        if p.grad is None:
+            continue
+        e = rel_l2(gsd[k].cpu(), p.grad)
+        worst = max(worst, (e, k))
+        assert e < grad_tolerance_n8(noise, k, 2e-2 if depth == 18 else 4e-2), (k, e, noise[k])
+    print("worst gradient rel-L2", worst)
+
+
+# ------------------------------------------------------------------ the reference's other geometries, full depth
+def _full_depth_forward(om, spec, x_cpu, **fwd_kw):
+    randomize(om, 1)
+    om.eval()
+    m = SlowFast(spec, dtype=torch.float32, device=DEV, backend=hip_backend())
+    m.load_state_dict(om.state_dict(), strict=True)
+    m.eval()
+    with torch.no_grad():
+        want = om([t for t in x_cpu])
+    got = m([t.to(DEV) for t in x_cpu], **fwd_kw).cpu()
+    return got, want
+
+
+def test_metric_geometry_forward_fp32():
+    """BASELINE.json's own geometry: canonical SlowFast-R50 8x8 (depth 50, 400 classes) on one 3 x 32 x 224^2 clip, fp32,
+    eval mode with non-trivial running statistics, PackPathway gathered inside the stem: <= 1e-3 of the oracle."""
+    torch.manual_seed(0)
+    om = o.canonical_slowfast_8x8(400)
+    frames = torch.randn(1, 3, 32, 224, 224, generator=torch.Generator().manual_seed(11))
+    randomize(om, 1)
+    om.eval()
+    m = SlowFast(arch.canonical_spec(400), dtype=torch.float32, device=DEV, backend=hip_backend())
+    m.load_state_dict(om.state_dict(), strict=True)
+    m.eval()
+    with torch.no_grad():
+        want = om(o.pack_pathway(frames))
+    fd = frames.to(DEV)
+    got = m([fd, fd], slow_t_index=pack_pathway_index(32, 4, DEV)).cpu()
+    assert got.shape == (1, 400)
+    assert rel_err(got, want) < FWD_TOL_F32
+
+
+@pytest.mark.parametrize("size,head", [(192, (17, 5, 5)), (64, (17, 1, 1))], ids=["HTAH-192", "Hand-64"])
+def test_reference_crop_geometries_forward_fp32(size, head):
+    """config/slowfast-HTAH.yaml (CropHTAH, 192^2: head map (.,17,5,5)) and slowfast-L/RHand.yaml (64^2: (.,17,1,1)), the
+    streams of the late-fusion ensemble (BASELINE config 5): depth 50, fp32, N=1, <= 1e-3 of the oracle."""
+    torch.manual_seed(0)
+    om = o.init_my_slowfast(249, (5, 15), (64, 8))
+    clips = torch.randn(1, 20, 21, size, size, generator=torch.Generator().manual_seed(size))
+    seen = {}
+    h = om.blocks[6].register_forward_pre_hook(lambda mod, inp: seen.update(shape=tuple(inp[0].shape)))
+    got, want = _full_depth_forward(om, arch.ref_spec(249), o.prepare_slowfast_data(clips))
+    h.remove()
+    assert seen["shape"] == (1, 2304) + head
+    assert got.shape == (1, 249) and rel_err(got, want) < FWD_TOL_F32
+
+
+def test_reference_geometry_train_step_gradients_fp32():
+    """the model train.py:114 builds at config/slowfast-Torso.yaml's geometry (depth 50, 5+15 channels, T=20, 128^2,
+    249 classes), N=2, train mode: loss, running statistics and EVERY live parameter's gradient against the oracle's
+    autograd -- the only full-depth check of the identity-block gradient accumulation (3/4/6/3 blocks per stage)."""
+    torch.manual_seed(0)
+    om = o.init_my_slowfast(249, (5, 15), (64, 8))
+    randomize(om, 2)
+    m = SlowFast(arch.ref_spec(249), dtype=torch.float32, device=DEV, backend=hip_backend())
+    m.load_state_dict(om.state_dict(), strict=True)
+    clips = torch.randn(2, 20, 21, 128, 128, generator=torch.Generator().manual_seed(3))
+    x = o.prepare_slowfast_data(clips)
+    labels = torch.tensor([17, 203])
+    m.train()
+    eng = m.engine
+    y_o, loss_o = oracle_train_step_with_engine_mask(om, eng, x, labels)
+    noise = oracle_grad_noise(om, eng, x, labels)
+    y_m = m([t.to(DEV) for t in x])
+    loss_m = torch.nn.functional.cross_entropy(y_m, labels.to(DEV))
+    loss_m.backward()
+    assert rel_err(y_m.detach().cpu(), y_o) < FWD_TOL_F32
+    assert abs(float(loss_m) - float(loss_o)) < 1e-3 * max(1.0, float(loss_o))
+    gsd = engine_grads_as_state_dict(eng)
+    errs = []
+    for k, p in om.named_parameters():
+        if p.grad is None:
+            assert ".residual." in k or ".res_unit." in k, k
+            continue
+        a, b = gsd[k].cpu().flatten().double(), p.grad.flatten().double()
+        errs.append((rel_l2(gsd[k].cpu(), p.grad), float(a @ b / (a.norm() * b.norm() + 1e-30)), noise[k], k))
+    errs.sort(reverse=True)
+    print("worst five (rel-L2, cosine, oracle noise, key):", errs[:5], "median", np.median([e[0] for e in errs]))
+    # 110 BN+ReLU layers at batch 2: the oracle's own gradients move by `noise` under a 1e-7 input perturbation; a wiring
+    # error (wrong tap, wrong block order, a missed accumulation) is O(1) in the tensors it touches and in all below them
+    assert np.median([e[0] for e in errs]) < 3e-2
+    for e, cos, nz, k in errs:
+        assert e < max(0.1, 6.0 * nz) and cos > 0.99 - 6.0 * nz, (k, e, cos, nz)
+    osd = om.state_dict()
+    for L in eng.layers:
+        assert rel_err(L.rm.cpu(), osd[L.cb.norm_key + ".running_mean"]) < 1e-3
+        assert rel_err(L.rv.cpu(), osd[L.cb.norm_key + ".running_var"]) < 1e-3
+
+
+@pytest.mark.parametrize("crop,batch", [("CropLHand", 300), ("CropLHandArm", 80), ("CropTorso", 55), ("CropHTAH", 55)])
+def test_yaml_batch_sizes_train_bf16(crop, batch):
+    """config/slowfast-*.yaml as written (BATCH_SIZE 300 @64^2, 80 @128^2, 55 @128^2 / 192^2; CLIP_LEN 20; 249 classes),
+    bf16: two fused steps at the full batch -- grid sizes, 32-bit offsets and workspaces at the reference's real sizes.
+    Properties only (the oracle would need minutes): loss starts at ln 249 and falls, weights stay finite."""
+    from video_classification_amd.config import crop_resize_dict
+    from video_classification_amd.train import TrainStep
+    size = crop_resize_dict[crop]
+    m = SlowFast(arch.ref_spec(249), dtype=torch.bfloat16, device=DEV, backend=hip_backend(), seed=2)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    clips = torch.randn(batch, 20, 21, size, size, generator=g, device=DEV, dtype=torch.bfloat16)
+    labels = torch.randint(0, 249, (batch,), generator=g, device=DEV)
+    x = clips.permute(0, 2, 1, 3, 4)
+    step = TrainStep(m.engine, lr=1e-3, use_graph=False)
+    m.train()
+    losses = [float(step(x[:, 0:5], x[:, 5:20], labels)) for _ in range(3)]
+    assert abs(losses[0] - np.log(249)) < 0.5 and losses[-1] < losses[0], losses
+    assert torch.isfinite(m.engine.P.data).all()
+    del m, step, clips
+    torch.cuda.empty_cache()

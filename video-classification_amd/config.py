@@ -3,7 +3,7 @@
 Mirrors /root/reference/config/defaults.py:4-60 (yacs CfgNode tree, get_cfg, get_override_cfg) and
 /root/reference/config/crop_cfg.py:22-57 (crop folder -> pixel size).  yacs is not installed in this image, so
 ``CfgNode`` is a small compatible subset: attribute access, clone(), merge_from_file(yaml), merge_from_list().
-New keys (MODEL.DTYPE, MODEL.ARCH, DIST.*) default to the reference's behaviour (fp32, its own geometry, 1 process).
+New keys (MODEL.DTYPE, MODEL.ARCH, MODEL.DEPTH, DIST.*) default to the reference's behaviour (fp32, its own geometry, 1 process).
 """
 from __future__ import annotations
 
@@ -95,7 +95,8 @@ _C.MODEL.INPUT_SIZE = 192
 _C.NUM_CPU = 18
 # ---- keys added by this engine; defaults reproduce the reference
 _C.MODEL.DTYPE = 'fp32'        # 'fp32' (reference precision) | 'bf16' (benchmark precision)
-_C.MODEL.ARCH = 'ref'          # 'ref' = init_my_slowfast geometry | 'canonical8x8' = SlowFast-R50 8x8
+_C.MODEL.ARCH = 'ref'          # 'ref' = init_my_slowfast geometry | 'canonical8x8' = SlowFast-R50 8x8 (BGR frames, PackPathway alpha 4)
+_C.MODEL.DEPTH = 50            # the reference hard-codes 50 (model/my_slowfast.py:98); 18 / 26 = the small test networks
 _C.DIST = CfgNode()
 _C.DIST.BUCKET_MB = 32         # gradient all-reduce bucket size
 

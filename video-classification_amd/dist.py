@@ -13,6 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 Range = Tuple[int, int]  # (offset, numel) in the arena
 
@@ -113,3 +114,51 @@ def shard_indices(num_items: int, rank: int, world: int, epoch_seed: int, shuffl
     per = num_items // world if drop_last else (num_items + world - 1) // world
     order = order[: per * world] if drop_last else (order + order[: per * world - num_items])
     return order[rank::world]
+
+
+class EpochShardSampler(torch.utils.data.Sampler):
+    """The train loader's sampler when world > 1: rank r draws shard_indices(len, r, world, seed + epoch) -- ONE
+    permutation of the epoch shared by all ranks (same seed), cut into disjoint per-rank subsets of equal length, so with
+    the loader's drop_last=True every rank runs the same number of steps (reference train.py:164: shuffle=True,
+    drop_last=True on a single process).  Call set_epoch(e) before every epoch."""
+
+    def __init__(self, num_items: int, rank: int, world: int, seed: int = 0, shuffle: bool = True, drop_last: bool = True):
+        self.num_items, self.rank, self.world, self.seed = num_items, rank, world, seed
+        self.shuffle, self.drop_last = shuffle, drop_last
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def indices(self) -> List[int]:
+        return shard_indices(self.num_items, self.rank, self.world, self.seed + self.epoch, self.shuffle, self.drop_last)
+
+    def __iter__(self):
+        return iter(self.indices())
+
+    def __len__(self):
+        per = self.num_items // self.world if self.drop_last else (self.num_items + self.world - 1) // self.world
+        return per
+
+
+class VideoShardSampler(torch.utils.data.Sampler):
+    """The test loader's sampler when world > 1: rank r evaluates videos r, r + world, r + 2 world, ... in order (no
+    padding, no duplicates: the ranks' counts may differ by one -- there is no collective inside the eval loop)."""
+
+    def __init__(self, num_items: int, rank: int, world: int):
+        self.num_items, self.rank, self.world = num_items, rank, world
+
+    def __iter__(self):
+        return iter(range(self.rank, self.num_items, self.world))
+
+    def __len__(self):
+        return len(range(self.rank, self.num_items, self.world))
+
+
+def gather_objects(obj, group=None) -> list:
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: eval scores, labels)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out

@@ -810,6 +810,8 @@ class Engine:
                 self._plans.clear()
             pl = self._build_plan(x_slow, x_fast, slow_t_index, train)
             pl.key = key
+            Engine._plan_serial += 1
+            pl.serial = Engine._plan_serial          # never reused (id() of a dropped plan can be)
             pl.bound = ptrs()
             pl.inputs = (x_slow, x_fast, slow_t_index)   # keep the bound tensors alive
             pl.graph_epoch = 0
@@ -833,6 +835,7 @@ class Engine:
         for op in ops:
             op(stream)
 
+    _plan_serial = 0
     NLANES = 4     # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway
 
     def lane_streams(self):

@@ -41,6 +41,9 @@ class SlowFast(torch.nn.Module):
         self.spec = spec
         self.engine = Engine(spec, dtype=dtype, device=device, backend=backend, seed=seed)
         self.arena = self.engine.P          # the one trainable tensor: all live parameters, kernel layout
+        # PackPathway ((deprecated)/(torchvideo)train.py:53-71) as a model attribute: when set, model([frames, frames])
+        # reads the slow pathway's frames frames[:, :, slow_t_index] inside the stem kernel (MODEL.ARCH canonical8x8)
+        self.slow_t_index: Optional[torch.Tensor] = None
 
     def forward(self, x, slow_t_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: [x_slow, x_fast] (SlowFast) or one (N,C,T,H,W) tensor (the single-pathway res3d network)."""
@@ -48,6 +51,8 @@ class SlowFast(torch.nn.Module):
             x_slow, x_fast = (x if torch.is_tensor(x) else x[0]), None
         else:
             x_slow, x_fast = x[0], x[1]
+        if slow_t_index is None:
+            slow_t_index = self.slow_t_index
         if self.training and torch.is_grad_enabled():
             return _SlowFastFn.apply(self.arena, self.engine, x_slow, x_fast, slow_t_index)
         with torch.no_grad():
@@ -73,9 +78,25 @@ def init_my_slowfast(cfg, input_channels, stem_dim_outs, device="cuda", backend=
     """Same call as the reference's ``init_my_slowfast(cfg, (5, 15), (64, 8))`` (train.py:114)."""
     assert len(input_channels) == 2 and len(stem_dim_outs) == 2, "two pathways (slow, fast)"
     spec = arch.ref_spec(num_class=cfg.CHALEARN.NUM_CLASS, input_channels=input_channels,
-                         stem_dim_outs=stem_dim_outs, fuse=bool(cfg.MODEL.FUSE))
+                         stem_dim_outs=stem_dim_outs, fuse=bool(cfg.MODEL.FUSE), depth=int(cfg.MODEL.get("DEPTH", 50)))
     dtype = _DTYPES[str(cfg.MODEL.get("DTYPE", "fp32")).lower()]
     return SlowFast(spec, dtype=dtype, device=device, backend=backend, seed=seed)
+
+
+def init_canonical_slowfast(cfg, device="cuda", backend=None, seed: int = 0, alpha: int = 4) -> SlowFast:
+    """MODEL.ARCH = 'canonical8x8': the hub model of (deprecated)/(torchvideo)train.py:249 (SlowFast-R50 8x8, the model
+    BASELINE.json's metric is quoted on) driven through the reference's config surface -- BGR frames of CLIP_LEN frames,
+    the slow pathway = every alpha-th frame (PackPathway), global head pools for the crop's size."""
+    t = int(cfg.CHALEARN.CLIP_LEN)
+    from .config import crop_resize_dict
+    s = crop_resize_dict[cfg.MODEL.R3D_INPUT] // 32
+    assert t % alpha == 0 and s >= 1, (t, s)
+    spec = arch.canonical_spec(num_class=cfg.CHALEARN.NUM_CLASS, depth=int(cfg.MODEL.get("DEPTH", 50)),
+                               head_pool_kernels=((t // alpha, s, s), (t, s, s)))
+    dtype = _DTYPES[str(cfg.MODEL.get("DTYPE", "fp32")).lower()]
+    m = SlowFast(spec, dtype=dtype, device=device, backend=backend, seed=seed)
+    m.slow_t_index = pack_pathway_index(t, alpha, device)
+    return m
 
 
 def slowfast_r50_8x8(num_class: int = 400, dtype=torch.bfloat16, device="cuda", backend=None, seed: int = 0) -> SlowFast:

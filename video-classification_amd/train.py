@@ -5,8 +5,11 @@ What differs from /root/reference/train.py, and why:
   * the step (forward, CrossEntropyLoss, zero_grad, backward, Adam -- train.py:225-231) is ONE flat schedule of
     libsfk kernels (``TrainStep``), optionally replayed as a hipGraph; loss and accuracy are accumulated on the
     device, so there is no ``.item()`` sync per step (train.py:236) -- they are read once per epoch;
-  * N>1: one process per GPU; the loaders shard clips over ranks and ``TrainStep`` all-reduces the gradient arena
-    over RCCL while backward is still running (dist.py).  The reference is single-GPU;
+  * N>1: one process per GPU; loaders the Trainer builds itself (from ``train_set`` / ``test_set`` or the reference's
+    dataset) shard one shuffled epoch over the ranks (``dist.EpochShardSampler``) and the test videos round-robin
+    (``dist.VideoShardSampler``, scores gathered to every rank); ``TrainStep`` all-reduces the gradient arena over RCCL
+    while backward is still running (dist.py); rank 0 writes checkpoints.  Loaders that are INJECTED are used as they are
+    (the caller shards them, or every rank sees everything).  The reference is single-GPU;
   * datasets are injected (``train_loader`` / ``test_loader``) or built from the reference's own
     ``ChalearnVideoDataset`` when that module is importable; items keep its contract: a dict
     {cfg.MODEL.R3D_INPUT: (T,21,S,S) float32, 'label': int} (lists of such dicts for the test set).
@@ -92,7 +95,7 @@ class TrainStep:
     def __call__(self, x_slow, x_fast, labels, slow_t_index=None) -> torch.Tensor:
         eng = self.eng
         pl = eng._plan_for(x_slow, x_fast, slow_t_index, True)
-        key = (id(pl), labels.data_ptr(), pl.graph_epoch)
+        key = (pl.serial, labels.data_ptr(), pl.graph_epoch)
         ent = self._cache.get(key)
         if ent is None:
             if len(self._cache) > 4:
@@ -127,20 +130,71 @@ class TrainStep:
 class ModelManager:
     """Name -> (init_model, prepare_data), as reference train.py:39-60.  'slowfast*' and 'res3d' (SURVEY.md section
     8f-4: hub slow_r50 with a 5-channel stem, train.py:79-89 / (deprecated)/train_3dresnet.py:47-51) run on this
-    engine; 'res2d' (a torchvision 2-D ResNet from torch.hub, train.py:64-76) is not a video path and raises."""
+    engine; 'res2d' (torchvision's 2-D ResNet-50 over T*C stacked frames, train.py:64-76) is host plumbing only
+    (res2d.py: BASELINE config 1, "CPU reference path, no GPU").  MODEL.ARCH = 'canonical8x8' swaps the SlowFast
+    geometry for the hub model's ((deprecated)/(torchvideo)train.py:44-71,249)."""
 
     def __init__(self, cfg, device="cuda", backend=None):
         self.cfg, self.device, self.backend = cfg, device, backend
         self._pre = None
         name = cfg.MODEL.NAME
-        if "slowfast" in name:
-            self.init_model = self._init_slowfast_model
-            self.prepare_data = self._prepare_slowfast_data
+        self.arch = str(cfg.MODEL.get("ARCH", "ref")).lower()
+        if self.arch not in ("ref", "canonical8x8"):
+            raise ValueError(f"MODEL.ARCH={self.arch!r}: 'ref' or 'canonical8x8'")
+        if name == "res2d":
+            self.init_model = self._init_res2d_model
+            self.prepare_data = self._prepare_res2d_data
         elif name == "res3d":
             self.init_model = self._init_res3d_model
             self.prepare_data = self._prepare_res3d_data
+        elif "slowfast" in name:
+            if self.arch == "canonical8x8":
+                self.init_model = self._init_canonical_model
+                self.prepare_data = self._prepare_canonical_data
+            else:
+                self.init_model = self._init_slowfast_model
+                self.prepare_data = self._prepare_slowfast_data
         else:
-            raise NotImplementedError(f"MODEL.NAME={name!r}: only the SlowFast path runs on this engine")
+            raise NotImplementedError()
+
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        """host -> device through PINNED memory, so the copy is a DMA that overlaps the previous step's kernels (a
+        pageable source makes `non_blocking=True` a synchronous staged copy: train.py:127's 1.5 GB batch would stall the
+        host for its whole duration).  Loaders built by the Trainer already pin (pin_memory=True)."""
+        if t.device.type == "cpu" and torch.device(self.device).type == "cuda" and not t.is_pinned():
+            t = t.pin_memory()
+        return t.to(self.device, non_blocking=True)
+
+    # ---- res2d (train.py:64-76): host plumbing, see res2d.py
+    def _init_res2d_model(self):
+        from .res2d import resnet50_2d
+        return resnet50_2d(in_channels=5 * int(self.cfg.CHALEARN.CLIP_LEN), num_classes=1000).to(
+            "cpu" if torch.device(self.device).type != "cuda" else self.device)
+
+    def _prepare_res2d_data(self, batch):
+        """(N,T,21,S,S)[:, :, :5] -> (N, T*5, S, S): frames stacked on the channel axis (train.py:70-76)."""
+        dev = "cpu" if torch.device(self.device).type != "cuda" else self.device
+        x = batch[self.cfg.MODEL.R3D_INPUT][:, :, :5].to(dev)
+        n, t, c, h, w = x.size()
+        return torch.reshape(x, (n, t * c, h, w)), batch['label'].to(dev)
+
+    # ---- canonical SlowFast-R50 8x8 (MODEL.ARCH)
+    def _init_canonical_model(self):
+        from .slowfast import init_canonical_slowfast
+        model = init_canonical_slowfast(self.cfg, device=self.device, backend=self.backend)
+        ckpt = Path('pretrained', 'SLOWFAST_8x8_R50.pyth')          # the hub checkpoint loads as it is (no surgery)
+        if ckpt.is_file():
+            state = torch.load(ckpt, map_location="cpu", weights_only=True)["model_state"]
+            if tuple(state['blocks.6.proj.weight'].shape) != (self.cfg.CHALEARN.NUM_CLASS, 2304):
+                del state['blocks.6.proj.weight'], state['blocks.6.proj.bias']
+            model.load_state_dict(state, strict=False)
+        return model
+
+    def _prepare_canonical_data(self, batch):
+        """(N,T,21,S,S) -> the BGR frames as one strided (N,3,T,S,S) view, handed over as BOTH pathways: the slow
+        pathway's PackPathway gather (model.slow_t_index) happens inside its stem kernel."""
+        x = torch.permute(self._h2d(batch[self.cfg.MODEL.R3D_INPUT]), [0, 2, 1, 3, 4])[:, 0:3]
+        return [x, x], self._h2d(batch['label'])
 
     @staticmethod
     def delete_mismatch(state_dict):
@@ -178,9 +232,9 @@ class ModelManager:
     def _prepare_res3d_data(self, batch):
         """(N,T,21,S,S) -> BGR+UV (N,5,T,S,S) strided view (train.py:85-89; 5 channels as train.py:72 / the 5-channel
         stem of :81)."""
-        x = batch[self.cfg.MODEL.R3D_INPUT].to(self.device, non_blocking=True)
+        x = self._h2d(batch[self.cfg.MODEL.R3D_INPUT])
         x = torch.permute(x, [0, 2, 1, 3, 4])
-        return x[:, 0:5], batch['label'].to(self.device, non_blocking=True)
+        return x[:, 0:5], self._h2d(batch['label'])
 
     def _prepare_slowfast_data(self, batch):
         """(N,T,21,S,S) -> [BGR+UV (N,5,T,S,S), flow (N,15,T,S,S)] strided views of the SAME memory; the depth channel
@@ -194,10 +248,14 @@ class ModelManager:
                 self._pre = DevicePreprocess(self.device, self.backend)
             x = self._pre(batch[key + "_u8"], batch.get("crop"))
         else:
-            x = batch[key].to(self.device, non_blocking=True)
+            x = self._h2d(batch[key])
         x = torch.permute(x, [0, 2, 1, 3, 4])
-        y_true = batch['label'].to(self.device, non_blocking=True)
+        y_true = self._h2d(batch['label'])
         return [x[:, 0:5], x[:, 5:20]], y_true
+
+
+def _identity(x):
+    return x
 
 
 class SyntheticChalearn(torch.utils.data.Dataset):
@@ -237,14 +295,22 @@ class SyntheticChalearn(torch.utils.data.Dataset):
 
 
 class Trainer:
-    def __init__(self, cfg, train_loader=None, test_loader=None, device="cuda", backend=None, use_graph: bool = False):
+    def __init__(self, cfg, train_loader=None, test_loader=None, device="cuda", backend=None, use_graph: bool = False,
+                 train_set=None, test_set=None, dist_backend: Optional[str] = None):
+        """train_set / test_set: datasets with the reference's item contract (default: the reference's own
+        ChalearnVideoDataset); the Trainer builds the loaders from them as train.py:149-170 does and, when WORLD_SIZE > 1,
+        shards them over the ranks.  train_loader / test_loader: ready loaders, used as they are."""
         self.debug = cfg.DEBUG
         self.num_workers = 0 if self.debug else min(cfg.NUM_CPU, 10)
         self.cfg = cfg
+        self.device = device
         self.batch_size = cfg.CHALEARN.BATCH_SIZE
-        self.rank, self.world, _ = sdist.init_process_group_from_env() if device != "cpu" else (0, 1, 0)
+        self.rank, self.world, _ = sdist.init_process_group_from_env(dist_backend)
+        self.epoch = 0
         if train_loader is None or test_loader is None:
-            train_loader, test_loader = self._reference_loaders()
+            if train_set is None or test_set is None:
+                train_set, test_set = self._reference_datasets()
+            train_loader, test_loader = self._make_loaders(train_set, test_set)
         self.train_loader, self.test_loader = train_loader, test_loader
         self.mm = ModelManager(cfg, device=device, backend=backend)
         self.model = self.mm.init_model()
@@ -252,23 +318,42 @@ class Trainer:
         self.ckpt_dir = Path(cfg.CHALEARN.ROOT, cfg.MODEL.LOGS, cfg.MODEL.CKPT_DIR, cfg.MODEL.NAME)
         self.max_historical_acc = 0.
         self.load_ckpt()
-        eng = self.model.engine
-        reducer = sdist.GradReducer(eng.G, bucket_mb=cfg.DIST.BUCKET_MB) if self.world > 1 else None
+        eng = getattr(self.model, "engine", None)
         # Adam is created AFTER the checkpoint load, its state is never saved (train.py:180-182)
-        self.step = TrainStep(eng, lr=cfg.MODEL.LR, use_graph=use_graph, reducer=reducer)
+        if eng is None:                                  # res2d: a plain torch module, the reference's own five lines
+            from .res2d import TorchStep
+            assert self.world == 1, "res2d is single-process host plumbing"
+            self.step = TorchStep(self.model, lr=cfg.MODEL.LR)
+        else:
+            reducer = sdist.GradReducer(eng.G, bucket_mb=cfg.DIST.BUCKET_MB) if self.world > 1 else None
+            self.step = TrainStep(eng, lr=cfg.MODEL.LR, use_graph=use_graph, reducer=reducer)
 
-    def _reference_loaders(self):
+    def _reference_datasets(self):
         try:
             from dataset.chalearn_dataset import ChalearnVideoDataset   # the reference's module, unchanged
         except Exception as e:  # cv2 / torchvision / label files missing
-            raise RuntimeError("no loaders were given and the reference's dataset.chalearn_dataset is not importable "
-                               f"here ({e}); pass train_loader/test_loader (e.g. SyntheticChalearn)") from e
-        tr = ChalearnVideoDataset(self.cfg, 'train')
-        te = ChalearnVideoDataset(self.cfg, 'test')
-        return (torch.utils.data.DataLoader(tr, batch_size=self.batch_size, shuffle=True, drop_last=True,
-                                            num_workers=self.num_workers),
-                torch.utils.data.DataLoader(te, batch_size=self.batch_size, shuffle=False, drop_last=False,
-                                            num_workers=self.num_workers, collate_fn=lambda x: x))
+            raise RuntimeError("no datasets / loaders were given and the reference's dataset.chalearn_dataset is not "
+                               f"importable here ({e}); pass train_set/test_set (e.g. SyntheticChalearn)") from e
+        return ChalearnVideoDataset(self.cfg, 'train'), ChalearnVideoDataset(self.cfg, 'test')
+
+    def _make_loaders(self, tr, te):
+        """train.py:164,170: train = shuffle + drop_last, test = whole videos, identity collate.  world > 1: one shuffled
+        epoch cut into disjoint per-rank shards (every rank runs the same number of steps), test videos round-robin."""
+        pin = torch.device(self.device).type == "cuda"
+        kw = dict(num_workers=self.num_workers, pin_memory=pin)
+        if self.world > 1:
+            self.train_sampler = sdist.EpochShardSampler(len(tr), self.rank, self.world, seed=0)
+            train = torch.utils.data.DataLoader(tr, batch_size=self.batch_size, sampler=self.train_sampler,
+                                                drop_last=True, **kw)
+            test = torch.utils.data.DataLoader(te, batch_size=self.batch_size, drop_last=False, collate_fn=_identity,
+                                               sampler=sdist.VideoShardSampler(len(te), self.rank, self.world), **kw)
+            test.sfk_shard = (self.rank, self.world, len(te))
+        else:
+            self.train_sampler = None
+            train = torch.utils.data.DataLoader(tr, batch_size=self.batch_size, shuffle=True, drop_last=True, **kw)
+            test = torch.utils.data.DataLoader(te, batch_size=self.batch_size, shuffle=False, drop_last=False,
+                                               collate_fn=_identity, **kw)
+        return train, test
 
     # ---- checkpoints: model weights only, 'acc%.3f_e%d.ckpt', newest by lexicographic sort, HTAH fallback
     def save_ckpt(self, epoch=0, acc=0.0):
@@ -298,12 +383,14 @@ class Trainer:
         self.step.reset_meters()
         seen = 0
         self.model.train()
+        if getattr(self, "train_sampler", None) is not None:
+            self.train_sampler.set_epoch(self.epoch)     # a new permutation of the epoch, the same on every rank
         for batch in self.train_loader:
             x, y_true = self.mm.prepare_data(batch)
-            if torch.is_tensor(x):                       # res3d: one pathway
+            if torch.is_tensor(x):                       # res3d / res2d: one input tensor
                 self.step(x, None, y_true)
             else:
-                self.step(x[0], x[1], y_true)
+                self.step(x[0], x[1], y_true, slow_t_index=self.model.slow_t_index)
             self.num_step += 1
             seen += int(y_true.shape[0])
             if self.debug:
@@ -311,6 +398,10 @@ class Trainer:
         # one device->host read per epoch instead of one per step
         loss_avg = float(self.step.loss_sum[0]) / max(self.step.steps, 1)
         correct = int(self.step.correct[0])
+        if self.world > 1:                               # the epoch's meters over all ranks (printed by every rank)
+            parts = sdist.gather_objects((loss_avg, correct, seen))
+            loss_avg = sum(p[0] for p in parts) / len(parts)
+            correct, seen = sum(p[1] for p in parts), sum(p[2] for p in parts)
         print(f'loss_avg: {round(loss_avg, 3)}')
         print(f'Train Accuracy: {round(correct / max(seen, 1), 3)}. ({correct} / {seen})')
         return loss_avg, correct / max(seen, 1)
@@ -321,6 +412,7 @@ class Trainer:
         for epoch in range(max_epoch):
             print(f'========== Training epoch {epoch}')
             self.num_step = 0
+            self.epoch = epoch
             self.train_epoch()
             acc = self.run_eval()['acc']
             if acc > self.max_historical_acc:
@@ -362,12 +454,43 @@ class Trainer:
             test_batch(default_collate(batch_collect))
         logits = torch.cat(logit_list, dim=0).contiguous()
         labels = torch.cat(true_list, dim=0).to(torch.int64).contiguous()
-        ps, pred, ncorrect = aggregate_scores(self.model.engine.be, logits, labels, samples_per_video, softmax=True)
+        shard = getattr(loader, "sfk_shard", None)
+        if shard is not None and shard[1] > 1 and not self.debug:
+            logits, labels, samples_per_video = self._gather_eval(logits, labels, samples_per_video, shard)
+        if hasattr(self.model, "engine"):
+            ps, pred, ncorrect = aggregate_scores(self.model.engine.be, logits, labels, samples_per_video, softmax=True)
+        else:
+            from .res2d import aggregate_scores_host
+            ps, pred, ncorrect = aggregate_scores_host(logits, labels, samples_per_video)
         ps, true_arr = ps.cpu().numpy(), labels.cpu().numpy()
         nvid = sum(1 for s_ in samples_per_video if s_ > 0)
         accuracy = ncorrect / max(nvid, 1)
         print(f'Test Accuracy: {round(float(accuracy), 3)}. ({ncorrect} / {nvid})')
         return {'ps': ps, 't': true_arr, 'acc': accuracy, 'sv': samples_per_video}
+
+
+    def _gather_eval(self, logits, labels, sv, shard):
+        """every rank evaluated videos rank, rank + world, ... (VideoShardSampler); rebuild the 1-rank order: video v is
+        the (v // world)-th video of rank v % world.  Small host objects (scores, labels, counts) travel; every rank ends
+        with the full result, so the best-accuracy bookkeeping of train() is the same everywhere."""
+        rank, world, total = shard
+        parts = sdist.gather_objects((logits.cpu(), labels.cpu(), list(sv)))
+        offs = []
+        for lg, lb, s_ in parts:
+            o = [0]
+            for c in s_:
+                o.append(o[-1] + int(c))
+            assert o[-1] == lg.shape[0] == lb.shape[0]
+            offs.append(o)
+        rows_l, rows_t, sv_all = [], [], []
+        for v in range(total):
+            r, j = v % world, v // world
+            lg, lb, s_ = parts[r]
+            rows_l.append(lg[offs[r][j]:offs[r][j + 1]])
+            rows_t.append(lb[offs[r][j]:offs[r][j + 1]])
+            sv_all.append(s_[j])
+        dev = logits.device
+        return (torch.cat(rows_l, 0).to(dev).contiguous(), torch.cat(rows_t, 0).to(dev).contiguous(), sv_all)
 
 
 def aggregate_scores(be, scores: torch.Tensor, labels: torch.Tensor, samples_per_video, softmax: bool):
