@@ -13,7 +13,9 @@
  *   - every buffer (inputs, outputs, workspaces) is owned by the caller; nothing is allocated, freed or
  *     retained past the call.  All pointers are DEVICE pointers unless a comment says "host".
  *   - calls are asynchronous on the caller's hipStream_t (passed as void*), never synchronise, and are
- *     safe to capture into a hipGraph.  No global mutable state.
+ *     safe to capture into a hipGraph.  No global mutable state: the only process-wide datum is the tuning table
+ *     below, written by sfk_init() BEFORE the first launch and read-only afterwards; no entry point reads the
+ *     environment.
  *   - return value: SFK_OK or a negative sfk_status; no exceptions, no abort.
  *   - feature maps are CHANNELS-LAST in HBM: element (n,t,h,w,c) of an sfk_fmap lives at
  *         ptr[ (((n*T + t)*H + h)*W + w) * ld + c_off + c ]
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 3
+#define SFK_ABI_VERSION 4
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -144,29 +146,6 @@ typedef struct {
 
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
 int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d); /* host-side query; <0 on error */
-
-/* ---------------------------------------------------------------------------------------------------------
- * sfk_stem_im2col -- gathers the stem's (kh x kw x cin) spatial window of every output pixel into a
- * channels-last patch matrix, reading the clip tensor in place with arbitrary element strides.
- * Replaces: the permute / channel-slice views of _prepare_slowfast_data (train.py:136-140), PackPathway's
- * frame gather ((deprecated)/(torchvideo)train.py:60-71) and the input side of the stem Conv3d
- * (my_slowfast.py:64-65).  The temporal taps of the stem (kt = 1 or 5) are applied afterwards by
- * sfk_conv_igemm on the patch matrix.
- *   out[n,t,ho,wo, (kh*KW + kw)*cin + ci] = src[n, ci, frame(t), ho*sh - ph + kh, wo*sw - pw + kw]  (0 outside)
- *   frame(t) = t_index ? t_index[t] : t;  columns >= KH*KW*cin of `out` (padding up to out.c) are zeroed.
- * src element (n,ci,t,h,w) is at src[n*sn + ci*sc + t*st + h*sh_ + w*sw_]  (element strides).
- */
-typedef struct {
-  const void* src;
-  int32_t src_dtype; /* SFK_F32 or SFK_BF16 */
-  int64_t sn, sc, st, sh, sw;
-  int32_t cin, t_in, h_in, w_in;
-  const int32_t* t_index; /* device, out.t entries, or NULL */
-  int32_t kh, kw, stride_h, stride_w, pad_h, pad_w;
-  sfk_fmap out; /* (n, t_out, ho, wo, c >= kh*kw*cin) */
-} sfk_im2col_desc;
-
-int sfk_stem_im2col(const sfk_im2col_desc* d, sfk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_stem_conv_fwd / sfk_stem_conv_wgrad -- the stem Conv3d (kt,7,7) stride (1,2,2) padding (kt/2,3,3), bias=False
@@ -348,6 +327,31 @@ int sfk_sparse_fusion_fwd(const float* x, const float* w, const float* b, float*
                           sfk_stream_t stream);
 int sfk_sparse_fusion_bwd(const float* x, const float* dy, float* dw, float* db, int32_t n, int32_t p, int32_t c,
                           sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * sfk_init -- the kernel-selection / tuning table ("an immutable kernel-selection table initialised
+ * once").  Every field has a measured default (sfk_default_tuning); a caller that wants an A/B experiment fills the
+ * struct and calls sfk_init ONCE per process before the first launch (calling it later is SFK_ERR_INVALID unless the
+ * table is unchanged).  The fields only move work between equivalent kernels / grid shapes / cache hints: results keep
+ * their meaning (summation order of split sums may change). */
+typedef struct {
+  int32_t igemm_short_k;      /* 5:    exact-count K loop for layers of <= this many K-steps                      */
+  int32_t igemm_small_k;      /* 0:    128x128 instead of 256x128 tiles up to this K (cin * taps)                 */
+  int32_t igemm_wide_store;   /* 1:    16-byte epilogue stores                                                    */
+  int32_t wgrad_target_8w;    /* 384:  resident-workgroup target of the 8-wave filter-gradient tile               */
+  int32_t wgrad_target_4w;    /* 512:  ... of the 4-wave tile                                                     */
+  int32_t wgrad_use_workspace;/* 1:    use sfk_wgrad_desc.workspace when given                                    */
+  int32_t wgrad_wide_co;      /* 1:    one 256 x 64 tile for wide-output / narrow-input layers                    */
+  int32_t bn_parts;           /* 1024: partial rows of the BatchNorm reductions (one resident generation)         */
+  int32_t nt_apply_mb;        /* 0:    non-temporal loads+stores in sfk_bn_apply for maps >= this many MB (-1 off) */
+  int32_t nt_reduce_mb;       /* 48:   non-temporal loads in sfk_bn_bwd_reduce                                    */
+  int32_t nt_bwd_apply_mb;    /* 150:  non-temporal loads+stores in sfk_bn_bwd_apply                              */
+  int32_t reserved;
+  int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
+} sfk_tuning;
+void sfk_default_tuning(sfk_tuning* out);
+int sfk_init(const sfk_tuning* t); /* NULL = defaults */
+void sfk_get_tuning(sfk_tuning* out);
 
 int sfk_abi_version(void);
 const char* sfk_status_string(int status);

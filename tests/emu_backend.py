@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from video_classification_amd._lib import ConvPass, FMap, Im2col, StemSrc, WgradPass, stem_kp
+from video_classification_amd._lib import ConvPass, FMap, StemSrc, WgradPass, stem_kp
 
 
 def _tile_bm(cout: int) -> int:
@@ -114,25 +114,6 @@ class EmuBackend:
                 dw[:, tap[3], :] += torch.einsum("nthwo,nthwc->oc", dY, _gather(X, rows, p.gs, tap))
         return run
 
-    def stem_im2col(self, p: Im2col):
-        def run(stream):
-            src = p.src.float()
-            if p.t_index is not None:
-                src = src.index_select(2, p.t_index.long())
-            n, c, t, h, w = src.shape
-            o = p.out
-            xp = torch.nn.functional.pad(src, (p.pad[1], p.pad[1], p.pad[0], p.pad[0]))
-            cols = torch.zeros(n, t, o.h, o.w, o.c)
-            for kh in range(p.kh):
-                for kw in range(p.kw):
-                    patch = xp[:, :, :, kh:kh + (o.h - 1) * p.stride[0] + 1:p.stride[0],
-                               kw:kw + (o.w - 1) * p.stride[1] + 1:p.stride[1]]      # n c t ho wo
-                    base = (kh * p.kw + kw) * c
-                    cols[..., base:base + c] = patch.permute(0, 2, 3, 4, 1)
-            o.view5().copy_(cols.to(o.dtype))
-        return run
-
-    # ------------------------------------------------------------------ stem convolution (direct)
     @staticmethod
     def _stem_x(p: StemSrc, dtype):
         x = p.src.to(dtype).float()          # the clip is rounded to the compute precision when the patch is staged

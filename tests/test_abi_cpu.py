@@ -38,7 +38,7 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(_lib._FMap) == 40            # void* + 8 x int32
     assert ctypes.sizeof(_lib._Tap) == 4
     assert _lib._ConvDesc.taps.size == 4 * _lib.SFK_MAX_TAPS
-    assert lib.sfk_abi_version() == 3
+    assert lib.sfk_abi_version() == 4
     assert lib.sfk_status_string(0) == b"ok" and lib.sfk_status_string(-2).startswith(b"unsupported")
 
 
@@ -62,3 +62,63 @@ def test_missing_library_fails_loudly(tmp_path):
             _lib.load(str(tmp_path / "libsfk.so"))
     finally:
         _lib._lib = saved
+
+
+def _integration_stub_structs():
+    """exec the ctypes snippet of INTEGRATION.md section 2 up to its last struct definition"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes as C, torch\n(.*?)```", text, flags=re.S).group(1)
+    head = code[: code.index("lib.sfk_conv_igemm.argtypes")]
+    head = re.sub(r"^lib = .*$", "", head, flags=re.M)
+    ns = {"C": ctypes}
+    exec(head, ns)
+    return ns
+
+
+def test_integration_md_stub_matches_the_abi(lib):
+    """the binding INTEGRATION.md tells a maintainer to write has the library's struct layouts: same field names in the
+    same order, same sizes (a struct one pointer short makes the library read past it)"""
+    from video_classification_amd import _lib
+    ns = _integration_stub_structs()
+    for doc_name, ours in (("FMap", _lib._FMap), ("Tap", _lib._Tap), ("BnBwdFuse", _lib._BnBwdFuse),
+                           ("ConvDesc", _lib._ConvDesc)):
+        doc = ns[doc_name]
+        assert [f[0] for f in doc._fields_] == [f[0] for f in ours._fields_], doc_name
+        assert ctypes.sizeof(doc) == ctypes.sizeof(ours), doc_name
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert f"sfk_abi_version() == {_lib.ABI_VERSION}" in text
+
+
+def test_header_struct_sizes_match_ctypes(lib, tmp_path):
+    """sizeof() of every struct include/sfk.h declares, from a C compiler, against the ctypes mirrors"""
+    import subprocess
+    from video_classification_amd import _lib
+    names = {"sfk_fmap": _lib._FMap, "sfk_tap": _lib._Tap, "sfk_bn_bwd_fuse": _lib._BnBwdFuse,
+             "sfk_conv_desc": _lib._ConvDesc, "sfk_wgrad_desc": _lib._WgradDesc, "sfk_stem_src": _lib._StemSrc,
+             "sfk_tuning": _lib._Tuning}
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "sfk.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)   # plain C, no HIP
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for n, ct in names.items():
+        assert int(out[n]) == ctypes.sizeof(ct), n
+
+
+def test_tuning_table_is_write_once_and_env_free(lib):
+    from video_classification_amd import _lib
+    d, cur = _lib._Tuning(), _lib._Tuning()
+    lib.sfk_default_tuning(ctypes.byref(d))
+    lib.sfk_get_tuning(ctypes.byref(cur))
+    assert (d.igemm_short_k, d.bn_parts, d.nt_reduce_mb, d.nt_bwd_apply_mb, d.pool_blocks) == (5, 1024, 48, 150, 1 << 20)
+    assert lib.sfk_init(ctypes.byref(cur)) == 0            # the same table again: fine
+    other = _lib._Tuning.from_buffer_copy(cur)
+    other.bn_parts = cur.bn_parts + 1
+    assert lib.sfk_init(ctypes.byref(other)) == -1         # a different one after load(): rejected, nothing changes
+    after = _lib._Tuning()
+    lib.sfk_get_tuning(ctypes.byref(after))
+    assert bytes(after) == bytes(cur)
+    # the library itself does not read the environment (include/sfk.h "Conventions")
+    for f in os.listdir(os.path.join(ROOT, "video-classification_amd", "csrc")):
+        assert "getenv" not in open(os.path.join(ROOT, "video-classification_amd", "csrc", f)).read(), f

@@ -4,6 +4,7 @@ crop-offset ranges, eval batching through the emulated backend)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import aux_ref
@@ -82,3 +83,9 @@ def test_sparse_dataset_layout_and_state_dict_keys(tmp_path):
     m2 = SparseModel(C, 3, device="cpu", backend=EmuBackend(), seed=2)
     m2.load_state_dict(ref.state_dict())
     assert torch.allclose(m2(x), ref(x), atol=1e-6)
+    # a foreign pickle that names anything but numpy's array reconstructors is refused, not executed
+    import os
+    with open(tmp_path / "slowfast-Evil", "wb") as f:
+        pickle.dump({"ps": os.getcwd, "t": labels, "sv": sv}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        SparseFusionDataset(tmp_path)

@@ -174,3 +174,36 @@ def test_trainer_uint8_batches_and_device_eval(hip, tmp_path):
     assert np.allclose(res["ps"].sum(1), 1.0, atol=1e-5) and 0.0 <= res["acc"] <= 1.0
     _, correct, acc = aux_ref.run_eval_scores(np.log(res["ps"]), res["t"], res["sv"])   # softmax(log p) == p
     assert abs(acc - res["acc"]) < 1e-9
+
+
+def test_prepare_data_host_to_device_copy_is_asynchronous(tmp_path):
+    """row f3 "pinned-memory H2D": with the compute stream busy, prepare_data (float32 batch from PAGEABLE host memory, and
+    the uint8 transport) returns while the stream is still running -- the copies are DMAs queued behind the kernels, the
+    host does not wait for them (train.py:127's `.cuda()` of a pageable tensor blocks for the whole transfer)."""
+    import time
+    from video_classification_amd.config import get_cfg
+    from video_classification_amd.train import ModelManager
+    cfg = get_cfg()
+    cfg.MODEL.NAME, cfg.MODEL.R3D_INPUT = "slowfast-Torso", "CropTorso"
+    mm = ModelManager(cfg, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    clips = torch.randn(6, 20, 21, 128, 128, generator=g)                    # 165 MB, pageable
+    u8 = torch.randint(0, 256, (6, 20, 128, 128, 21), generator=g, dtype=torch.uint8)
+    labels = torch.arange(6)
+    assert not clips.is_pinned()
+    mm.prepare_data({"CropTorso": clips[:1], "label": labels[:1]})          # warm the allocators / load the kernels
+    mm.prepare_data({"CropTorso_u8": u8[:1], "label": labels[:1]})
+    torch.cuda.synchronize()
+    for batch in ({"CropTorso": clips, "label": labels}, {"CropTorso_u8": u8, "label": labels}):
+        torch.cuda._sleep(int(3e9))                                           # ~1 s of busy compute stream
+        busy = torch.cuda.Event()
+        busy.record()
+        t0 = time.perf_counter()
+        x, y = mm.prepare_data(batch)
+        host_s = time.perf_counter() - t0
+        assert not busy.query(), f"prepare_data waited for the compute stream ({host_s:.3f} s)"
+        torch.cuda.synchronize()
+        assert x[0].shape == (6, 5, 20, 128, 128) and x[1].shape == (6, 15, 20, 128, 128)
+        if "CropTorso" in batch:
+            assert torch.equal(x[0].cpu(), clips.permute(0, 2, 1, 3, 4)[:, 0:5])
+        assert torch.equal(y.cpu(), labels)

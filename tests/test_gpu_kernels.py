@@ -7,7 +7,7 @@ import torch
 
 from emu_backend import EmuBackend
 from helpers import rel_err
-from video_classification_amd._lib import ConvPass, FMap, Im2col, StemSrc, WgradPass, stem_kp
+from video_classification_amd._lib import ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from video_classification_amd.plan import ConvGeom, dgrad_passes, fwd_pass, wgrad_taps
 
 pytestmark = pytest.mark.gpu
@@ -169,25 +169,6 @@ def test_conv_rejects_bad_descriptors(hip):
     _, x6 = fmap_pair(1, 6, 1, 4, 4, torch.bfloat16, gen)                                           # cin % 8 != 0
     with pytest.raises(SfkError):
         hip.conv_igemm(ConvPass(x6, y, (1, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0), [(0, 0, 0, 0)], w, 1, 6, 8))(stream())
-
-
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("src_dtype", DTYPES, ids=["src_f32", "src_bf16"])
-def test_stem_im2col(hip, dtype, src_dtype):
-    gen = torch.Generator().manual_seed(3)
-    emu = EmuBackend()
-    clips = mk((2, 6, 21, 18, 22), src_dtype, gen)                  # dataset memory N,T,C,H,W
-    for chan, t_index in (((0, 5), None), ((5, 20), None), ((0, 3), torch.tensor([0, 2, 5], dtype=torch.int32))):
-        view = clips.permute(0, 2, 1, 3, 4)[:, chan[0]:chan[1]]     # NCTHW view, nothing copied (train.py:136-140)
-        cin = chan[1] - chan[0]
-        t_out = 6 if t_index is None else 3
-        kpad = (49 * cin + 7) // 8 * 8
-        oc, og = fmap_pair(2, kpad, t_out, 9, 11, dtype, gen, fill=5.0)
-        emu.stem_im2col(Im2col(view, t_index, 7, 7, (2, 2), (3, 3), oc))(0)
-        vg = clips.to(DEV).permute(0, 2, 1, 3, 4)[:, chan[0]:chan[1]]
-        hip.stem_im2col(Im2col(vg, None if t_index is None else t_index.to(DEV), 7, 7, (2, 2), (3, 3), og))(stream())
-        torch.cuda.synchronize()
-        assert torch.equal(og.view5().float().cpu(), oc.view5().float())      # a pure gather (+ one rounding): bit-exact
 
 
 STEM_CASES = [
@@ -616,3 +597,31 @@ def test_conv_output_relu_bitmap(hip, case):
     # a strided (scattering) pass cannot take a bitmap and says so
     sc = ConvPass(xg, ya, (t, (h + 1) // 2, (w + 1) // 2), (1, 1, 1), (1, 2, 2), (0, 0, 0), list(sp.taps), wgt.to(DEV), g.wtaps, cin, cout)
     assert not hip.conv_relu_out_supported(sc)
+
+
+def test_conv_operand_beyond_2gib_runs_register_staged(hip):
+    """An activation map of >= 2 GiB (batches beyond the benchmark's) cannot use the LDS-DMA kernel (31-bit offsets); the
+    128-wide bf16 tile then runs register-staged instead of failing mid-step.  Checked against the SAME layer run per sample
+    (each half is < 2 GiB and takes the DMA kernel), statistics rows included."""
+    n, t, h, w, cin, cout = 2, 32, 128, 128, 1024, 128
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xb = torch.randn(n * t * h * w * cin, generator=g, device=DEV, dtype=torch.bfloat16)
+    assert xb.numel() * 2 >= 0x7FF00000
+    wt = (torch.randn(cout * cin, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    taps, rows, one = [(0, 0, 0, 0)], (t, h, w), (1, 1, 1)
+
+    def run(x: FMap):
+        y = FMap(torch.zeros(x.pixels * cout, dtype=torch.bfloat16, device=DEV), x.n, t, h, w, cout)
+        p = ConvPass(x, y, rows, one, one, (0, 0, 0), taps, wt, 1, cin, cout)
+        mt = hip.conv_igemm_mtiles(p)
+        p.stats = torch.zeros(mt * cout * 2, device=DEV)
+        hip.conv_igemm(p)(stream())
+        torch.cuda.synchronize()
+        return y.buf, p.stats.view(mt, cout, 2).sum(0)
+
+    y_all, st_all = run(FMap(xb, n, t, h, w, cin))
+    per = t * h * w * cin
+    parts = [run(FMap(xb[i * per:(i + 1) * per], 1, t, h, w, cin)) for i in range(n)]
+    y_ref = torch.cat([p_[0] for p_ in parts])
+    assert rel_err(y_all.float().cpu(), y_ref.float().cpu()) < 1e-2 and float(y_ref.float().abs().max()) > 1.0
+    assert rel_err(st_all.cpu(), (parts[0][1] + parts[1][1]).cpu()) < 1e-4

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 3        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 4        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -132,17 +132,6 @@ def stem_kp(cin: int, kt: int) -> int:
     return (kt * cin * 7 + 3) // 4 * 4 * 8
 
 
-@dataclass
-class Im2col:
-    src: torch.Tensor        # any strided view indexed (n, c, t, h, w)
-    t_index: Optional[torch.Tensor]
-    kh: int
-    kw: int
-    stride: Tuple[int, int]
-    pad: Tuple[int, int]
-    out: FMap
-
-
 # ----------------------------------------------------------------------------- ctypes mirror of sfk.h
 class _FMap(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("t", C.c_int32), ("h", C.c_int32),
@@ -172,20 +161,28 @@ class _WgradDesc(C.Structure):
                 ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
-class _Im2colDesc(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("src_dtype", C.c_int32), ("sn", C.c_int64), ("sc", C.c_int64),
-                ("st", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("cin", C.c_int32), ("t_in", C.c_int32),
-                ("h_in", C.c_int32), ("w_in", C.c_int32), ("t_index", C.c_void_p), ("kh", C.c_int32),
-                ("kw", C.c_int32), ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32),
-                ("pad_w", C.c_int32), ("out", _FMap)]
-
-
 class _StemSrc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_dtype", C.c_int32), ("sn", C.c_int64), ("sc", C.c_int64),
                 ("st", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("cin", C.c_int32), ("t_in", C.c_int32),
                 ("h_in", C.c_int32), ("w_in", C.c_int32), ("t_index", C.c_void_p), ("t_len", C.c_int32),
                 ("kt", C.c_int32)]
 
+
+class _Tuning(C.Structure):
+    """sfk_tuning: the write-once kernel-selection table of sfk_init (defaults = the measured best)."""
+    _fields_ = [("igemm_short_k", C.c_int32), ("igemm_small_k", C.c_int32), ("igemm_wide_store", C.c_int32),
+                ("wgrad_target_8w", C.c_int32), ("wgrad_target_4w", C.c_int32), ("wgrad_use_workspace", C.c_int32),
+                ("wgrad_wide_co", C.c_int32), ("bn_parts", C.c_int32), ("nt_apply_mb", C.c_int32),
+                ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("reserved", C.c_int32),
+                ("pool_blocks", C.c_int64)]
+
+
+# experiment knobs (tools/gpu_ab_env.sh): read HERE, once, on the host side of the boundary -- the library itself never
+# reads the environment (include/sfk.h); name -> sfk_tuning field
+TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK_WIDE": "igemm_wide_store",
+              "SFK_WGT8": "wgrad_target_8w", "SFK_WGT4": "wgrad_target_4w", "SFK_WGWS_LIB": "wgrad_use_workspace",
+              "SFK_WG_WIDECO": "wgrad_wide_co", "SFK_BN_PARTS": "bn_parts", "SFK_NT_APPLY_MB": "nt_apply_mb",
+              "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)
@@ -198,7 +195,6 @@ SIGNATURES = {
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
-    "sfk_stem_im2col": [C.POINTER(_Im2colDesc), _PV],
     "sfk_stem_kp": [_I32, _I32],
     "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
     "sfk_stem_conv_fwd": [C.POINTER(_StemSrc), _PV, _P_FMAP, _PF, _PV],
@@ -228,10 +224,14 @@ SIGNATURES = {
     "sfk_sparse_fusion_fwd": [_PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
     "sfk_sparse_fusion_bwd": [_PF, _PF, _PF, _PF, _I32, _I32, _I32, _PV],
     "sfk_filter_refresh": [_PF, _PV, _PV, _I32, _PV, _I32, _I32, _PV],
+    "sfk_default_tuning": [C.POINTER(_Tuning)],
+    "sfk_get_tuning": [C.POINTER(_Tuning)],
+    "sfk_init": [C.POINTER(_Tuning)],
     "sfk_abi_version": [],
     "sfk_status_string": [C.c_int],
 }
-_RESTYPE = {"sfk_status_string": C.c_char_p, "sfk_conv_wgrad_workspace_bytes": C.c_int64}
+_RESTYPE = {"sfk_status_string": C.c_char_p, "sfk_conv_wgrad_workspace_bytes": C.c_int64, "sfk_default_tuning": None,
+            "sfk_get_tuning": None}
 
 _lib = None
 
@@ -248,11 +248,26 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = _RESTYPE.get(name, C.c_int)
+        fn.restype = _RESTYPE[name] if name in _RESTYPE else C.c_int
     if lib.sfk_abi_version() != ABI_VERSION:
         raise SfkError("libsfk ABI version mismatch")
+    t = _Tuning()
+    lib.sfk_default_tuning(C.byref(t))
+    for env, fld in TUNING_ENV.items():
+        if os.environ.get(env) is not None:
+            setattr(t, fld, int(os.environ[env]))
+    st = lib.sfk_init(C.byref(t))                # once per process, before the first launch
+    if st != 0:
+        raise SfkError(f"sfk_init: {lib.sfk_status_string(st).decode()}")
     _lib = lib
     return lib
+
+
+def tuning() -> _Tuning:
+    """the table the loaded library runs with (sfk_get_tuning)"""
+    t = _Tuning()
+    load().sfk_get_tuning(C.byref(t))
+    return t
 
 
 def _check(st: int, what: str):
@@ -368,26 +383,6 @@ class HipBackend:
                 _check(st, "sfk_conv_wgrad")
         return run
 
-    def stem_im2col(self, p: Im2col):
-        s = p.src
-        assert s.dim() == 5
-        d = _Im2colDesc()
-        d.src, d.src_dtype = s.data_ptr(), _DT[s.dtype]
-        d.sn, d.sc, d.st, d.sh, d.sw = s.stride()
-        d.cin, d.t_in, d.h_in, d.w_in = s.shape[1], s.shape[2], s.shape[3], s.shape[4]
-        d.t_index = _ptr(p.t_index)
-        d.kh, d.kw = p.kh, p.kw
-        d.stride_h, d.stride_w = p.stride
-        d.pad_h, d.pad_w = p.pad
-        d.out = _c_fmap(p.out)
-        fn = self.lib.sfk_stem_im2col
-
-        def run(stream, _d=C.byref(d), _keep=(d, p)):
-            st = fn(_d, stream)
-            if st:
-                _check(st, "sfk_stem_im2col")
-        return run
-
     @staticmethod
     def _c_stem(p: StemSrc) -> _StemSrc:
         s = p.src
@@ -457,7 +452,7 @@ class HipBackend:
         rows_b = 256 // cgs_b
         parts = (y.pixels + rows_b * 16 - 1) // (rows_b * 16)
         cchunks = (cgs + 255) // 256
-        parts = min(parts, max(1, int(os.environ.get("SFK_BN_PARTS", "1024")) // cchunks))
+        parts = min(parts, max(1, int(tuning().bn_parts) // cchunks))
         if max_parts > 0:
             parts = min(parts, max_parts)
         return max(1, parts)

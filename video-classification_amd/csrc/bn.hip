@@ -9,10 +9,8 @@
 // push other lanes' working sets out), a small one stays cached -- bn_bwd_apply re-reads what bn_bwd_reduce just read.
 
 namespace {
-// thresholds in MB of ONE map (pixels * channels * element size); knobs: SFK_NT_APPLY_MB / SFK_NT_RED_MB / SFK_NT_BAPP_MB
-inline int nt_hint(const sfk_fmap* f, const char* env, int default_mb, int bits) {
-  const char* e = getenv(env);
-  const int64_t mb = e ? atoi(e) : default_mb;
+// thresholds in MB of ONE map (pixels * channels * element size): sfk_tuning.nt_apply_mb / nt_reduce_mb / nt_bwd_apply_mb
+inline int nt_hint(const sfk_fmap* f, int64_t mb, int bits) {
   const int64_t bytes = sfk_fmap_pixels(f) * f->c * (f->dtype == SFK_BF16 ? 2 : 4);
   return (mb >= 0 && bytes >= (mb << 20)) ? bits : 0;
 }
@@ -55,7 +53,7 @@ inline dim3 chan_grid(int cgs, int64_t pixels, int max_parts, int* nparts) {
   const int rows_b = 256 / cgs_b;
   int64_t parts = (pixels + (int64_t)rows_b * 16 - 1) / ((int64_t)rows_b * 16);  // >= 16 pixels per thread
   const int cchunks = (cgs + 255) / 256;
-  static const int cap_all = getenv("SFK_BN_PARTS") ? atoi(getenv("SFK_BN_PARTS")) : 1024;   // A/B knob (engine.MAX_PARTS follows it)
+  const int cap_all = sfk_tune().bn_parts;   // (engine.MAX_PARTS follows it)
   int64_t cap = cap_all / cchunks;
   if (cap < 1) cap = 1;
   if (parts > cap) parts = cap;
@@ -507,7 +505,7 @@ int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
   grid.x = span_blocks(y->c / DT<T>::VEC, px);      // one span per thread: no grid-stride loop
   const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
   const int mode = !res ? 0 : (rs ? 2 : 1);
-  const int nt = nt_hint(y, "SFK_NT_APPLY_MB", 0, 3);
+  const int nt = nt_hint(y, sfk_tune().nt_apply_mb, 3);
 #define SFK_APPLY(R, A)                                                                                                      \
   do {                                                                                                                     \
     if (nt) hipLaunchKernelGGL((bn_apply_kernel<T, R, A, 3>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits); \
@@ -557,7 +555,7 @@ int launch_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms,
   const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, max_parts, &np), blk(256);
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), z = fm_of(dzo);
   const int mask = bits ? 3 : (ms ? 2 : (relu ? 1 : 0));
-  const int nt = nt_hint(y, "SFK_NT_RED_MB", 48, 2);
+  const int nt = nt_hint(y, sfk_tune().nt_reduce_mb, 2);
 #define SFK_RED(M, W)                                                                                                        \
   do {                                                                                                                     \
     if (nt) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 2>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits); \
@@ -585,7 +583,7 @@ int launch_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, 
   grid.x = span_blocks(y->c / DT<T>::VEC, px);      // one span per thread: no grid-stride loop
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), o = fm_of(dy);
   const int mask = ms ? 2 : (relu ? 1 : 0);
-  const int nt = nt_hint(y, "SFK_NT_BAPP_MB", 150, 3);
+  const int nt = nt_hint(y, sfk_tune().nt_bwd_apply_mb, 3);
 #define SFK_APP(M)                                                                                                           \
   do {                                                                                                                     \
     if (nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, 3>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, invstd, scale, shift, coef); \

@@ -264,6 +264,153 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
   }
 }
 
+// The plain epilogue of BOTH conv kernels (one copy: the register-staged and the LDS-DMA kernel differ only in how the
+// tiles reach LDS): channels-last stores of the accumulators -- 4 consecutive co per lane per fragment, 8 after the
+// permlane swap (`wide`) -- with the optional += of `accumulate`, the optional output ReLU bitmap (EPI == 2), and the
+// per-tile BatchNorm partial statistics.
+template <typename T, int EPI, int FM, int FN, int BM, int BN, int WM, int WN, bool RING_BUSY>
+__device__ __forceinline__ void epilogue_plain(const ConvK& k, const f32x4 (&acc)[FN][FM], float* red, int mt, int nt,
+                                               int wm, int wn, int lane, int tid) {
+  const int l15 = lane & 15, g = lane >> 4;
+  T* __restrict__ yp = static_cast<T*>(k.y);
+  const int co_w = nt * BN + wn * (BN / WN);
+  const bool wide = sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store;
+  int64_t poffs[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
+      poffs[j] = (int64_t)m * k.yld + k.yoff;
+    } else {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
+    }
+  }
+  bf16x8 oldv[FM][(FN + 1) / 2];
+  if (wide && k.accumulate) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+      if (m < k.M) {
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
+      }
+    }
+  }
+  // ReLU bitmap of the output (lin_out only: the pixel index is the row): byte [pixel][co / VEC], fetched with the old
+  // values, before the first store
+  static_assert(EPI != 2 || FN <= 8, "one packed bitmap word per fragment row");
+  uint32_t mb[EPI == 2 ? FM : 1];            // byte i/2 = the bitmap byte of this lane's store i (packed: registers)
+  bool masked = false;
+  if constexpr (EPI == 2) {
+    masked = wide && k.obits;
+    if (masked) {
+      // the wave's FN*16 channels of a pixel are FN*2 consecutive bitmap bytes: one aligned 4- or 8-byte load per pixel
+      // row (the 4 lanes of a pixel fetch the same word) when the channel count allows, else one byte load per store
+      const bool word = (FN == 4 || FN == 2) && (k.cout % (FN * 16)) == 0;
+      const int sh = 8 * (2 * (g & 1) + (g >> 1));          // this lane's byte within each 4-byte group
+      if (word) {
+        // branch-free (rows past M re-read the last row; nothing is stored for them): a load under a branch makes hipcc
+        // drain vmcnt after it, one serial round trip per pixel row
+        uint2 w[FM];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          const uint8_t* bp = k.obits + (int64_t)(m < k.M ? m : k.M - 1) * (k.cout >> 3) + (co_w >> 3);
+          if constexpr (FN == 4) w[j] = *reinterpret_cast<const uint2*>(bp);
+          else w[j] = make_uint2(*reinterpret_cast<const uint32_t*>(bp), 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < FM; ++j) mb[j] = ((w[j].x >> sh) & 255u) | (((w[j].y >> sh) & 255u) << 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+          mb[j] = 0;
+          if (m < k.M) {
+#pragma unroll
+            for (int i = 0; i < FN; i += 2) {
+              const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+              if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    if (m < k.M) {
+      const int64_t poff = poffs[j];
+      if (wide) {
+#pragma unroll
+        for (int i = 0; i < FN; i += 2)
+          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2],
+                      (EPI == 2 && masked) ? (int)((mb[EPI == 2 ? j : 0] >> (8 * (i / 2))) & 255u) : -1);
+      } else {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int co = co_w + 16 * i + 4 * g;
+          if (co < k.cout) {
+            int mbits = -1;
+            if constexpr (EPI == 2 && sizeof(T) == 4) {
+              if (k.obits) mbits = k.obits[(int64_t)m * (k.cout >> 2) + (co >> 2)] & 15;
+            }
+            store4(yp + poff + co, acc[i][j], k.accumulate != 0, mbits);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- BatchNorm partial statistics of this tile (rows past M accumulated zeros, so they add nothing)
+  if (k.stats) {
+    // red = [WM][BN][2] floats, aliases the staging ring: the register-staged kernel still has LDS reads of its last
+    // K-step in flight (RING_BUSY), the DMA kernel has drained and met at a barrier already
+    if constexpr (RING_BUSY) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (l15 == 15) {
+          const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < k.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) {
+          s1 += red[(w_ * BN + tid) * 2 + 0];
+          s2 += red[(w_ * BN + tid) * 2 + 1];
+        }
+        float* o = k.stats + ((int64_t)mt * k.cout + co) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+    }
+  }
+}
+
 // EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb), 2 output ReLU bitmap (out_relu_bits) -- own
 // instantiations: the extra epilogue state must not cost the plain kernel registers (the 256x128 tile sits at 128 VGPRs)
 template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, int EPI = 0>
@@ -456,142 +603,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
-  T* __restrict__ yp = static_cast<T*>(k.y);
-  const int co_w = nt * BN + wn * (BN / WN);
-  const bool wide = sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store;
-  int64_t poffs[FM];
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-    if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
-      poffs[j] = (int64_t)m * k.yld + k.yoff;
-    } else {
-      uint32_t q1, rw_, q2, rh_, n_, rt_;
-      k.drw.divmod((uint32_t)m, q1, rw_);
-      k.drh.divmod(q1, q2, rh_);
-      k.drt.divmod(q2, n_, rt_);
-      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-      poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
-    }
-  }
-  bf16x8 oldv[FM][(FN + 1) / 2];
-  if (wide && k.accumulate) {
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-      if (m < k.M) {
-#pragma unroll
-        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
-      }
-    }
-  }
-  // ReLU bitmap of the output (lin_out only: the pixel index is the row): byte [pixel][co / VEC], fetched with the old
-  // values, before the first store
-  static_assert(EPI != 2 || FN <= 8, "one packed bitmap word per fragment row");
-  uint32_t mb[EPI == 2 ? FM : 1];            // byte i/2 = the bitmap byte of this lane's store i (packed: registers)
-  bool masked = false;
-  if constexpr (EPI == 2) {
-    masked = wide && k.obits;
-    if (masked) {
-      // the wave's FN*16 channels of a pixel are FN*2 consecutive bitmap bytes: one aligned 4- or 8-byte load per pixel
-      // row (the 4 lanes of a pixel fetch the same word) when the channel count allows, else one byte load per store
-      const bool word = (FN == 4 || FN == 2) && (k.cout % (FN * 16)) == 0;
-      const int sh = 8 * (2 * (g & 1) + (g >> 1));          // this lane's byte within each 4-byte group
-      if (word) {
-        // branch-free (rows past M re-read the last row; nothing is stored for them): a load under a branch makes hipcc
-        // drain vmcnt after it, one serial round trip per pixel row
-        uint2 w[FM];
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-          const uint8_t* bp = k.obits + (int64_t)(m < k.M ? m : k.M - 1) * (k.cout >> 3) + (co_w >> 3);
-          if constexpr (FN == 4) w[j] = *reinterpret_cast<const uint2*>(bp);
-          else w[j] = make_uint2(*reinterpret_cast<const uint32_t*>(bp), 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < FM; ++j) mb[j] = ((w[j].x >> sh) & 255u) | (((w[j].y >> sh) & 255u) << 8);
-      } else {
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-          mb[j] = 0;
-          if (m < k.M) {
-#pragma unroll
-            for (int i = 0; i < FN; i += 2) {
-              const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
-              if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
-            }
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-    if (m < k.M) {
-      const int64_t poff = poffs[j];
-      if (wide) {
-#pragma unroll
-        for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2],
-                      (EPI == 2 && masked) ? (int)((mb[EPI == 2 ? j : 0] >> (8 * (i / 2))) & 255u) : -1);
-      } else {
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          const int co = co_w + 16 * i + 4 * g;
-          if (co < k.cout) {
-            int mbits = -1;
-            if constexpr (EPI == 2 && sizeof(T) == 4) {
-              if (k.obits) mbits = k.obits[(int64_t)m * (k.cout >> 2) + (co >> 2)] & 15;
-            }
-            store4(yp + poff + co, acc[i][j], k.accumulate != 0, mbits);
-          }
-        }
-      }
-    }
-  }
-
-  // ---- BatchNorm partial statistics of this tile (rows past M accumulated zeros, so they add nothing)
-  if (k.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2], aliases the ring: wait for the last K-step's LDS reads
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const float v = acc[i][j][r];
-          s1 += v;
-          s2 += v * v;
-        }
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (l15 == 15) {
-          const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
-          red[(wm * BN + col) * 2 + 0] = s1;
-          red[(wm * BN + col) * 2 + 1] = s2;
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int co = nt * BN + tid;
-      if (co < k.cout) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w_ = 0; w_ < WM; ++w_) {
-          s1 += red[(w_ * BN + tid) * 2 + 0];
-          s2 += red[(w_ * BN + tid) * 2 + 1];
-        }
-        float* o = k.stats + ((int64_t)mt * k.cout + co) * 2;
-        o[0] = s1;
-        o[1] = s2;
-      }
-    }
-  }
+  epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, true>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -800,156 +812,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-out-of-range) look-ahead DMAs before LDS is reused
   __syncthreads();
 
-  // ---- epilogue (identical to the register-staged kernel)
+  // ---- epilogue
   if constexpr (EPI == 1) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
-  T* __restrict__ yp = static_cast<T*>(k.y);
-  const int co_w = nt * BN + wn * (BN / WN);
-  const bool wide = sizeof(T) == 2 && (FN % 2) == 0 && k.wide_store;
-  int64_t poffs[FM];
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-    if (k.lin_out) {                 // the rows ARE the output pixels (stride-1 passes): no coordinates needed
-      poffs[j] = (int64_t)m * k.yld + k.yoff;
-    } else {
-      uint32_t q1, rw_, q2, rh_, n_, rt_;
-      k.drw.divmod((uint32_t)m, q1, rw_);
-      k.drh.divmod(q1, q2, rh_);
-      k.drt.divmod(q2, n_, rt_);
-      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-      poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
-    }
-  }
-  bf16x8 oldv[FM][(FN + 1) / 2];
-  if (wide && k.accumulate) {
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-      if (m < k.M) {
-#pragma unroll
-        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
-      }
-    }
-  }
-  // ReLU bitmap of the output (lin_out only: the pixel index is the row): byte [pixel][co / VEC], fetched with the old
-  // values, before the first store
-  static_assert(EPI != 2 || FN <= 8, "one packed bitmap word per fragment row");
-  uint32_t mb[EPI == 2 ? FM : 1];            // byte i/2 = the bitmap byte of this lane's store i (packed: registers)
-  bool masked = false;
-  if constexpr (EPI == 2) {
-    masked = wide && k.obits;
-    if (masked) {
-      // the wave's FN*16 channels of a pixel are FN*2 consecutive bitmap bytes: one aligned 4- or 8-byte load per pixel
-      // row (the 4 lanes of a pixel fetch the same word) when the channel count allows, else one byte load per store
-      const bool word = (FN == 4 || FN == 2) && (k.cout % (FN * 16)) == 0;
-      const int sh = 8 * (2 * (g & 1) + (g >> 1));          // this lane's byte within each 4-byte group
-      if (word) {
-        // branch-free (rows past M re-read the last row; nothing is stored for them): a load under a branch makes hipcc
-        // drain vmcnt after it, one serial round trip per pixel row
-        uint2 w[FM];
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-          const uint8_t* bp = k.obits + (int64_t)(m < k.M ? m : k.M - 1) * (k.cout >> 3) + (co_w >> 3);
-          if constexpr (FN == 4) w[j] = *reinterpret_cast<const uint2*>(bp);
-          else w[j] = make_uint2(*reinterpret_cast<const uint32_t*>(bp), 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < FM; ++j) mb[j] = ((w[j].x >> sh) & 255u) | (((w[j].y >> sh) & 255u) << 8);
-      } else {
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-          mb[j] = 0;
-          if (m < k.M) {
-#pragma unroll
-            for (int i = 0; i < FN; i += 2) {
-              const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
-              if (co < k.cout) mb[j] |= (uint32_t)k.obits[(int64_t)m * (k.cout >> 3) + (co >> 3)] << (8 * (i / 2));
-            }
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-    if (m < k.M) {
-      const int64_t poff = poffs[j];
-      if (wide) {
-#pragma unroll
-        for (int i = 0; i < FN; i += 2)
-          store8_pair(yp + poff, co_w + 16 * i, k.cout, acc[i][j], acc[(i + 1) % FN][j], g, k.accumulate != 0, oldv[j][i / 2],
-                      (EPI == 2 && masked) ? (int)((mb[EPI == 2 ? j : 0] >> (8 * (i / 2))) & 255u) : -1);
-      } else {
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          const int co = co_w + 16 * i + 4 * g;
-          if (co < k.cout) {
-            int mbits = -1;
-            if constexpr (EPI == 2 && sizeof(T) == 4) {
-              if (k.obits) mbits = k.obits[(int64_t)m * (k.cout >> 2) + (co >> 2)] & 15;
-            }
-            store4(yp + poff + co, acc[i][j], k.accumulate != 0, mbits);
-          }
-        }
-      }
-    }
-  }
-  if (k.stats) {
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const float v = acc[i][j][r];
-          s1 += v;
-          s2 += v * v;
-        }
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (l15 == 15) {
-          const int col = wn * (BN / WN) + 16 * i + 4 * g + r;
-          red[(wm * BN + col) * 2 + 0] = s1;
-          red[(wm * BN + col) * 2 + 1] = s2;
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int co = nt * BN + tid;
-      if (co < k.cout) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w_ = 0; w_ < WM; ++w_) {
-          s1 += red[(w_ * BN + tid) * 2 + 0];
-          s2 += red[(w_ * BN + tid) * 2 + 1];
-        }
-        float* o = k.stats + ((int64_t)mt * k.cout + co) * 2;
-        o[0] = s1;
-        o[1] = s2;
-      }
-    }
-  }
+  epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, false>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
 }
 
-struct TileSel { int bm, bn; };
-inline TileSel pick_tile(int cout, int dtype, int64_t M, int ktot = 1 << 30) {
-  // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
-  // once the grid still fills the chip
-  static const int small_k = getenv("SFK_SMALLK") ? atoi(getenv("SFK_SMALLK")) : 0;
-  if (cout > 64 && dtype == SFK_BF16 && M >= 256 * 128 && ktot > small_k) return {256, 128};
-  if (cout > 64) return {128, 128};
-  if (cout > 32) return {256, 64};
-  if (cout > 16) return {256, 32};
-  return {256, 16};
+struct TileSel { int bm, bn; bool dma; };
+// ONE place decides tile and kernel family for a descriptor: sfk_conv_igemm_mtiles (rows of stats / partials) and the
+// launch must agree.
+inline TileSel pick_tile(const sfk_conv_desc* d) {
+  const int cout = d->cout, dtype = d->x.dtype, ktot = d->ntaps * d->cin;
+  const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
+  if (cout > 64 && dtype == SFK_BF16) {
+    // the LDS-DMA ring addresses < 2 GiB per operand (soffset rides on top of a 31-bit voffset); larger maps -- batches
+    // beyond the benchmark's -- run the register-staged 128x128 kernel, which only needs the 4 GiB of validate()
+    const int64_t wbytes = (int64_t)d->cout * d->wtaps * d->cin * 2;
+    if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || wbytes >= 0x7FF00000ll) return {128, 128, false};
+    // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
+    // once the grid still fills the chip
+    if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k) return {256, 128, true};
+    return {128, 128, true};
+  }
+  if (cout > 64) return {128, 128, false};
+  if (cout > 32) return {256, 64, false};
+  if (cout > 16) return {256, 32, false};
+  return {256, 16, false};
 }
 
 // the fused BatchNorm-backward epilogue exists for bf16 tiles with an even number of co fragments and 16-byte stores
@@ -1057,23 +947,19 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
     k.bn_relu = d->bnb.relu;
     k.bn_mean = d->bnb.mean; k.bn_invstd = d->bnb.invstd; k.bn_scale = d->bnb.scale; k.bn_shift = d->bnb.shift;
   }
-  static const int kshort = getenv("SFK_KSHORT") ? atoi(getenv("SFK_KSHORT")) : 5;   // A/B knob
-  k.kshort = kshort;
+  k.kshort = sfk_tune().igemm_short_k;
   k.lin_out = lin_out_of(d);
-  static const int wide_ok = getenv("SFK_WIDE") ? atoi(getenv("SFK_WIDE")) : 1;   // A/B knob
+  const int wide_ok = sfk_tune().igemm_wide_store;
   k.wide_store = (wide_ok || k.obits) && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  const TileSel ts = pick_tile(d->cout, d->x.dtype, k.M, d->ntaps * d->cin);
+  const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
   const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
   // bf16: LDS-DMA ring for the wide tile; narrow outputs keep the register-staged kernel (higher occupancy, tiny K)
-  if (sizeof(T) == 2 && ts.bn == 128) {
-    if (k.xbytes < 0x7FF00000u && k.wbytes < 0x7FF00000u) return launch_dma(k, ts.bm, grid, s);
-    return SFK_ERR_UNSUPPORTED;   // the DMA path addresses < 2 GiB per operand
-  }
+  if (ts.dma) return launch_dma(k, ts.bm, grid, s);
   if (k.bn_parts) {          // fused BatchNorm-backward reduce (bf16, cout > 16: tiles of 32..128 output channels)
     if constexpr (sizeof(T) == 2) {
       if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
@@ -1112,7 +998,7 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int st = validate(d);
   if (st != SFK_OK) return st;
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
-  const int bm = pick_tile(d->cout, d->x.dtype, M, d->ntaps * d->cin).bm;
+  const int bm = pick_tile(d).bm;
   return (int)((M + bm - 1) / bm);
 }
 

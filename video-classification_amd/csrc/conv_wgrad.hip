@@ -535,8 +535,7 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   const int base = cotiles * k.citiles;
   // pixel splits: one resident generation of workgroups (2 x 256 CUs for the 8-wave tile, 3 x 256 for the 4-wave one).
   // Every split adds a full copy of the tile to the fp32 atomic traffic (~1.3 TB/s chip-wide), so do not over-split.
-  static const int target8 = getenv("SFK_WGT8") ? atoi(getenv("SFK_WGT8")) : 384;   // A/B knobs: resident-block targets
-  static const int target4 = getenv("SFK_WGT4") ? atoi(getenv("SFK_WGT4")) : 512;
+  const int target8 = sfk_tune().wgrad_target_8w, target4 = sfk_tune().wgrad_target_4w;   // resident-block targets
   int splits = ((NW == 8 ? target8 : target4) + base - 1) / base;
   const int max_splits = (k.nchunks + 7) / 8;
   if (splits > max_splits) splits = max_splits;
@@ -610,7 +609,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.dbytes = (uint32_t)sfk_fmap_bytes(&d->dy);
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  static const int use_ws = getenv("SFK_WGWS") ? atoi(getenv("SFK_WGWS")) : 1;   // A/B knob
+  const int use_ws = sfk_tune().wgrad_use_workspace;
   k.ws = use_ws ? reinterpret_cast<float4*>(d->workspace) : nullptr;
   const int cols = d->ntaps * d->cin;
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
@@ -620,7 +619,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   }
   if constexpr (sizeof(T) == 2) {
     // wide output, narrow input (slow res2 conv_c: 64 -> 256): ONE tile holds all of dW, so x and dY are each read once
-    static const int wide_co = getenv("SFK_WG_WIDECO") ? atoi(getenv("SFK_WG_WIDECO")) : 1;   // A/B knob
+    const int wide_co = sfk_tune().wgrad_wide_co;
     if (wide_co && d->cout >= 256 && cols > 32 && cols <= 64) return launch_cfg<T, 256, 64, 1>(k, d, s, dry);
   }
   if (cols <= 32) {

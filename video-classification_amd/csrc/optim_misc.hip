@@ -1,4 +1,6 @@
-// Fused Adam over the flat parameter arena, filter re-layout for the data-gradient pass, casts, stem im2col.
+// Fused Adam over the flat parameter arena, filter re-layout for the data-gradient pass, casts, the tuning table.
+#include <string.h>
+
 #include "sfk_common.h"
 
 namespace {
@@ -118,50 +120,6 @@ __global__ __launch_bounds__(256) void filter_refresh_kernel(const float* __rest
   }
 }
 
-struct Im2colK {
-  const void* src;
-  int64_t sn, sc, st, sh, sw;
-  int cin, t_in, h_in, w_in;
-  const int32_t* t_index;
-  int kh, kw, sth, stw, ph, pw;
-  void* out;
-  int ot, oh, ow, oc, old, ooff;
-  int kreal;  // kh*kw*cin
-  FastDiv dcg, dow, doh, dot, dcin, dkw;
-};
-
-template <typename S, typename D>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const Im2colK k, int64_t total) {
-  constexpr int VEC = DT<D>::VEC;
-  const S* sp = static_cast<const S*>(k.src);
-  D* op = static_cast<D*>(k.out);
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    uint32_t pix, cg, q1, wo, q2, ho, n, t;
-    k.dcg.divmod((uint32_t)idx, pix, cg);
-    k.dow.divmod(pix, q1, wo);
-    k.doh.divmod(q1, q2, ho);
-    k.dot.divmod(q2, n, t);
-    const int frame = k.t_index ? k.t_index[t] : (int)t;
-    const S* base = sp + (int64_t)n * k.sn + (int64_t)frame * k.st;
-    Vec16<D> o;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const int col = (int)cg * VEC + i;
-      float f = 0.f;
-      if (col < k.kreal && (unsigned)frame < (unsigned)k.t_in) {
-        uint32_t tapi, ci, khi, kwi;
-        k.dcin.divmod((uint32_t)col, tapi, ci);
-        k.dkw.divmod(tapi, khi, kwi);
-        const int hi = (int)ho * k.sth - k.ph + (int)khi, wi = (int)wo * k.stw - k.pw + (int)kwi;
-        if ((unsigned)hi < (unsigned)k.h_in && (unsigned)wi < (unsigned)k.w_in)
-          f = (float)base[(int64_t)ci * k.sc + (int64_t)hi * k.sh + (int64_t)wi * k.sw];
-      }
-      o.set(i, f);
-    }
-    o.store(op + (int64_t)pix * k.old + k.ooff + cg * VEC);
-  }
-}
-
 inline unsigned grid_for(int64_t total, int per_thread = 1) {
   int64_t b = (total + 256ll * per_thread - 1) / (256ll * per_thread);
   if (b > 16384) b = 16384;
@@ -242,34 +200,31 @@ extern "C" int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream) {
   return hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream)) == hipSuccess ? SFK_OK : SFK_ERR_LAUNCH;
 }
 
-extern "C" int sfk_stem_im2col(const sfk_im2col_desc* d, sfk_stream_t stream) {
-  if (!d || !d->src || !sfk_fmap_ok(&d->out) || !dtype_ok(d->src_dtype)) return SFK_ERR_INVALID;
-  if (d->cin <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0)
+// ------------------------------------------------------------------ tuning table (sfk_init)
+namespace {
+sfk_tuning g_tuning = {5, 0, 1, 384, 512, 1, 1, 1024, 0, 48, 150, 0, 1ll << 20};
+bool g_tuning_set = false;
+}  // namespace
+const sfk_tuning& sfk_tune() { return g_tuning; }
+
+extern "C" void sfk_default_tuning(sfk_tuning* out) {
+  if (out) *out = sfk_tuning{5, 0, 1, 384, 512, 1, 1, 1024, 0, 48, 150, 0, 1ll << 20};
+}
+
+extern "C" void sfk_get_tuning(sfk_tuning* out) {
+  if (out) *out = g_tuning;
+}
+
+extern "C" int sfk_init(const sfk_tuning* t) {
+  sfk_tuning want;
+  sfk_default_tuning(&want);
+  if (t) want = *t;
+  if (want.bn_parts < 1 || want.wgrad_target_8w < 1 || want.wgrad_target_4w < 1 || want.pool_blocks < 1 ||
+      want.igemm_short_k < 0)
     return SFK_ERR_INVALID;
-  if (d->out.c < d->kh * d->kw * d->cin) return SFK_ERR_INVALID;
-  if (d->out.h != (d->h_in + 2 * d->pad_h - d->kh) / d->stride_h + 1 ||
-      d->out.w != (d->w_in + 2 * d->pad_w - d->kw) / d->stride_w + 1)
-    return SFK_ERR_INVALID;
-  if (!d->t_index && d->out.t != d->t_in) return SFK_ERR_INVALID;
-  if (!sfk_fmap_vec_ok(&d->out)) return SFK_ERR_UNSUPPORTED;
-  const int vec = sfk_vec_of(d->out.dtype);
-  const int64_t total = sfk_fmap_pixels(&d->out) * (d->out.c / vec);
-  if (total >= (1ll << 31)) return SFK_ERR_UNSUPPORTED;
-  Im2colK k;
-  k.src = d->src; k.sn = d->sn; k.sc = d->sc; k.st = d->st; k.sh = d->sh; k.sw = d->sw;
-  k.cin = d->cin; k.t_in = d->t_in; k.h_in = d->h_in; k.w_in = d->w_in; k.t_index = d->t_index;
-  k.kh = d->kh; k.kw = d->kw; k.sth = d->stride_h; k.stw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w;
-  k.out = d->out.ptr; k.ot = d->out.t; k.oh = d->out.h; k.ow = d->out.w; k.oc = d->out.c; k.old = d->out.ld;
-  k.ooff = d->out.c_off; k.kreal = d->kh * d->kw * d->cin;
-  k.dcg.set(d->out.c / vec); k.dow.set(d->out.w); k.doh.set(d->out.h); k.dot.set(d->out.t);
-  k.dcin.set(d->cin); k.dkw.set(d->kw);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(grid_for(total)), blk(256);
-  if (d->src_dtype == SFK_F32 && d->out.dtype == SFK_F32) hipLaunchKernelGGL((stem_im2col_kernel<float, float>), grid, blk, 0, s, k, total);
-  else if (d->src_dtype == SFK_F32 && d->out.dtype == SFK_BF16) hipLaunchKernelGGL((stem_im2col_kernel<float, bf16_t>), grid, blk, 0, s, k, total);
-  else if (d->src_dtype == SFK_BF16 && d->out.dtype == SFK_F32) hipLaunchKernelGGL((stem_im2col_kernel<bf16_t, float>), grid, blk, 0, s, k, total);
-  else hipLaunchKernelGGL((stem_im2col_kernel<bf16_t, bf16_t>), grid, blk, 0, s, k, total);
-  SFK_CHECK_LAUNCH();
+  if (g_tuning_set) return memcmp(&want, &g_tuning, sizeof(want)) == 0 ? SFK_OK : SFK_ERR_INVALID;   // write-once
+  g_tuning = want;
+  g_tuning_set = true;
   return SFK_OK;
 }
 

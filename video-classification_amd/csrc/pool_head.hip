@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, co
 
 inline unsigned grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
-  static const int64_t cap = getenv("SFK_POOL_BLOCKS") ? atoll(getenv("SFK_POOL_BLOCKS")) : (1ll << 20);   // one pass per thread (a grid-stride loop over 8192 blocks: +8 % on the max-pool backward)
+  const int64_t cap = sfk_tune().pool_blocks;   // one pass per thread (a grid-stride loop over 8192 blocks: +8 % on the max-pool backward)
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (unsigned)b;

@@ -5,6 +5,9 @@
 
 #include "sfk.h"
 
+// the process-wide tuning table of sfk_init (optim_misc.hip); read-only after the first launch
+__attribute__((visibility("hidden"))) const sfk_tuning& sfk_tune();
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -25,7 +25,11 @@ from ._lib import BN_FOLD_ROWS, BnBwdFuse, ConvPass, FMap, StemSrc, WgradPass, s
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
-MAX_PARTS = int(os.environ.get("SFK_BN_PARTS", "1024"))
+
+
+def _max_parts() -> int:
+    from ._lib import tuning
+    return int(tuning().bn_parts)       # partial rows of the BatchNorm reductions (sfk_tuning.bn_parts)
 
 
 @dataclass
@@ -132,6 +136,7 @@ class Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._plans: Dict[tuple, Plan] = {}
         self._build_params(seed)
+        self.max_parts = _max_parts() if getattr(self.be, "name", "") == "hip" else 1024
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
         # BatchNorm-backward reduce folded into the dgrad epilogues (sfk_conv_desc.bnb): removes 3.3 ms of reduce kernels,
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
@@ -402,12 +407,12 @@ class Engine:
             parts, np_ = reduced
             dz_inplace = True
         else:
-            parts = self._buf(f"bparts.{tag}", MAX_PARTS * L.c * 2, torch.float32)
+            parts = self._buf(f"bparts.{tag}", self.max_parts * L.c * 2, torch.float32)
             if bits is not None:
                 assert dz_inplace
                 mask_src = None
             run, np_ = self.be.bn_bwd_reduce(da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu,
-                                             da if dz_inplace else None, parts, MAX_PARTS, relu_bits=bits)
+                                             da if dz_inplace else None, parts, self.max_parts, relu_bits=bits)
             pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
                           bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0))
                           + (rec.y.pixels * L.c // self.kvec if bits is not None else 0))

@@ -7,7 +7,8 @@ What it replaces (reference dataset/chalearn_dataset.py):
            ``sfk_u8_normalize_crop``;
   :73-85   transforms.RandomCrop(size, padding = size // 10) on the (T, 21, S, S) clip tensor: one (top, left) per clip,
            zeros (of the NORMALISED tensor) outside the frame -> the kernel's per-clip crop offsets;
-  train.py:127  the 1.5 GB pageable float32 H2D copy of a 55-clip batch -> a uint8 copy a quarter of that size.
+  train.py:127  the 1.5 GB pageable float32 H2D copy of a 55-clip batch -> a uint8 copy a quarter of that size, staged in
+           pinned host memory so that it is an asynchronous DMA.
 The reference's ChalearnVideoDataset is untouched: a loader that can hand over its ``img_cat`` frames (HWC uint8, :113)
 feeds ``DevicePreprocess``; loaders that deliver float32 batches keep the reference path (ModelManager.prepare_data).
 torchvision is not installed here, so ToTensor / Normalize / RandomCrop are restated from their documented semantics;
@@ -49,13 +50,20 @@ class DevicePreprocess:
         self.be, self.device, self.out_dtype = backend, torch.device(device), out_dtype
         self.lut = normalize_lut().to(self.device)
 
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        """through pinned host memory: the uint8 batch crosses PCIe as an asynchronous DMA behind the previous step's
+        kernels (from pageable memory `non_blocking=True` is a synchronous staged copy)"""
+        if t.device.type == "cpu" and self.device.type == "cuda" and not t.is_pinned():
+            t = t.pin_memory()
+        return t.to(self.device, non_blocking=True)
+
     def __call__(self, frames_u8: torch.Tensor, crop: Optional[torch.Tensor] = None, padding: Optional[int] = None):
         assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 5
         n, t, h, w, c = frames_u8.shape
-        x = frames_u8.to(self.device, non_blocking=True).contiguous()
+        x = self._h2d(frames_u8).contiguous()
         if crop is not None:
             padding = h // 10 if padding is None else padding
-            crop = crop.to(self.device, dtype=torch.int32, non_blocking=True).contiguous()
+            crop = self._h2d(crop.to(torch.int32)).contiguous()
             assert tuple(crop.shape) == (n, 2)
         out = torch.empty(n, t, c, h, w, dtype=self.out_dtype, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0

@@ -9,7 +9,8 @@
 The SparseModel's parameters live in one fp32 arena [w: (class, part) | b: (class)]; ``state_dict`` speaks the
 reference's keys ``fcs.<c>.weight`` (1, P) / ``fcs.<c>.bias`` (1,).  One training step = 5 kernel launches
 (forward, softmax-CE, zero, backward, Adam); nothing returns to the host until the epoch's accuracy is read.
-The pickles read here are the ones this package's ResultSaver wrote (same dict contract as the reference's).
+The result files keep the reference's pickle format (dict of numpy arrays); they are read with an unpickler that
+resolves numpy's array reconstructors only.
 """
 from __future__ import annotations
 
@@ -22,6 +23,29 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 import torch.utils.data
+
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """The result files keep the reference's format (a pickled dict of numpy arrays, train_sparse.py:82-84), so that a
+    reference-side reader and this one exchange files; reading them must not execute what a foreign pickle names:
+    only the numpy array / dtype / scalar reconstructors resolve, every other global is refused."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.numeric", "_frombuffer"),
+                ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"sparse-fusion result file names {module}.{name}: only numpy arrays are accepted")
+
+
+def load_result_file(path) -> dict:
+    with Path(path).open('rb') as f:
+        d = _ArraysOnlyUnpickler(f).load()
+    if not isinstance(d, dict) or not {'ps', 't', 'sv'} <= set(d):
+        raise ValueError(f"{path}: not a run_eval result dict")
+    return d
+
 
 PART_YAMLS = ['slowfast-HTAH', 'slowfast-LHandArm', 'slowfast-LHand', 'slowfast-RHandArm', 'slowfast-RHand']  # :35
 
@@ -54,8 +78,7 @@ class SparseFusionDataset(torch.utils.data.Dataset):
     def __init__(self, res_folder) -> None:
         parts = []
         for p in glob.glob(str(Path(res_folder, '*'))):
-            with Path(p).open('rb') as f:
-                parts.append((Path(p).stem, pickle.load(f)))      # files written by ResultSaver above
+            parts.append((Path(p).stem, load_result_file(p)))     # the reference's file format, arrays only
         parts.sort(key=lambda x: x[0])                                # by part name (train_sparse.py:121)
         self.part_names = [p[0] for p in parts]
         self.T_cp = np.stack([p[1]['t'] for p in parts])[0, :]        # labels are the same for every part
