@@ -8,8 +8,11 @@ gradient all-reduce, Adam) of SlowFast-R50 8x8 on synthetic 3 x 32 x 224^2 bf16 
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment); weak scaling (32 clips per GPU); inputs
 are resident in HBM before the timed region; rank 0 prints ONE JSON line.  Besides the contract keys the line holds
-  roofline      the dominant kernel (by device time in one step): algorithmic FLOPs / summed launch durations, both
-                measured live with HIP events on the launch stream in a separate, untimed, instrumented step
+  roofline      the dominant kernel class (by device time in one step): algorithmic bytes (FLOPs) / summed launch
+                durations, measured live with HIP events on each kernel's own launch stream in instrumented steps of the
+                PRODUCTION 4-lane schedule right after the timed region (the same thing rocprofv3 --kernel-trace of this
+                command sees: profiles/rNN_class_stats.json holds its per-class average durations)
+  chip          all HBM bytes of a step (committed PMC run) / this run's step time, vs 8 TB/s and vs the fused ideal
   stages        the same accounting for every kernel class (MFMA TFLOP/s for convs, HBM GB/s for BN / pool stages)
   cpu_baseline  the oracle (torch.nn restatement of the reference path) running the same training step on the host
                 cores, on a bounded sample (N=1 only)
@@ -31,58 +34,92 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 achievable (same guide)
 MFMA_KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
 
 
-def pmc_traffic(kind: str):
-    """HBM bytes per launch of kernel class `kind` from the newest committed PMC summary (tools/gpu_traffic.sh:
-    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this very command, gfx950 correction applied)."""
+FUSED_IDEAL_GB_PER_STEP = 0.791 * 3 * 32   # fully fused ideal 0.791 GB/clip forward, x3 for a training step, 32 clips
+
+
+def pmc_summary():
+    """The newest committed PMC summary (tools/gpu_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over
+    this very command, gfx950 correction applied) -> (dict, path relative to the repo) or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None, None
     try:
         with open(files[-1]) as f:
-            c = json.load(f)["classes"].get(kind)
-    except (OSError, ValueError, KeyError):
+            return json.load(f), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError):
         return None, None
+
+
+def pmc_traffic(kind: str):
+    """HBM bytes per launch of kernel class `kind` from that summary."""
+    c, src = pmc_summary()
+    c = (c or {}).get("classes", {}).get(kind)
     if not c or not c.get("launches"):
         return None, None
-    return int(c["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    return int(c["hbm_bytes_per_launch"]), src
 
 
-def instrumented_step(step, pl, frames, labels, idx):
-    """One eager step with a HIP event pair around every kernel of the schedule (same stream the kernels launch on).
-    Returns {kind: {'ms', 'flops', 'bytes', 'launches'}}."""
+def instrumented_step(step, pl, frames, labels, idx, schedule="lanes"):
+    """One step with a HIP event pair around every kernel of the schedule, recorded on the stream the kernel is launched
+    on.  schedule = "lanes": the PRODUCTION schedule (4 concurrent lanes, trunk on its high-priority stream) -- a kernel's
+    duration includes what it loses to the other lanes' kernels, which is what `rocprofv3 --kernel-trace` of this command
+    reports too; "serial": everything on one stream (each kernel alone on the chip; the per-layer tuning view).
+    Returns {kind: {'ms', 'flops', 'bytes', 'launches', 'roof_ms'}}."""
+    from video_classification_amd.engine import Wait
     eng = step.eng
-    st = eng._stream()
     ops = step._build(pl, labels)
     ev = []
+    per_layer = bool(os.environ.get("SFK_PER_LAYER"))
+    lanes = schedule == "lanes" and eng.two_streams
 
     def timed(oplist):
-        from video_classification_amd.engine import Wait
-        per_layer = bool(os.environ.get("SFK_PER_LAYER"))
+        streams = eng.lane_streams() if lanes else [torch.cuda.current_stream()]
+        handles = [s_.cuda_stream for s_ in streams]
         for op, meta, lane in zip(oplist, oplist.meta, oplist.lane):
-            if meta is None and (not per_layer or isinstance(op, Wait)):
-                op(st)
+            li = lane if lanes else 0
+            if isinstance(op, Wait):
+                if lanes:
+                    e = torch.cuda.Event()
+                    e.record(streams[op.on])
+                    streams[op.lane].wait_event(e)
+                continue
+            if meta is None and not per_layer:
+                op(handles[li])
                 continue
             if meta is None:
                 meta = {"kind": "misc", "layer": getattr(op, "sfk_name", "?")}   # finalize / pool / head kernels: per-layer dump only
             meta = dict(meta, lane=lane)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            op(st)
-            b.record()
+            a.record(streams[li])
+            op(handles[li])
+            b.record(streams[li])
             ev.append((meta, a, b))
 
-    eng.drop_seed.add_(1)
-    timed(pl.fwd)
-    ops["zero_loss"](st); ops["loss"](st); ops["zero_grad"](st)
-    timed(pl.bwd)
-    ops["adam"](st)
+    def body():
+        st = eng._stream()
+        eng.drop_seed.add_(1)
+        timed(pl.fwd)
+        ops["zero_loss"](st); ops["loss"](st); ops["zero_grad"](st)
+        timed(pl.bwd)
+        ops["adam"](st)
+
+    torch.cuda.synchronize()
+    if lanes and step._trunk is not None:
+        cur = torch.cuda.current_stream()
+        step._trunk.wait_stream(cur)
+        with torch.cuda.stream(step._trunk):
+            body()
+        cur.wait_stream(step._trunk)
+    else:
+        body()
     torch.cuda.synchronize()
     out = {}
-    if os.environ.get("SFK_PER_LAYER"):
+    if per_layer:
         rows = [dict(meta, ms=a.elapsed_time(b)) for meta, a, b in ev]
-        os.makedirs(os.path.dirname(os.environ["SFK_PER_LAYER"]) or ".", exist_ok=True)
-        with open(os.environ["SFK_PER_LAYER"], "w") as f:
+        path = os.environ["SFK_PER_LAYER"] + ("" if schedule == "serial" else ".lanes")
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
             json.dump(rows, f)
     for meta, a, b in ev:
         kind = meta["kind"]
@@ -133,6 +170,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (serialises the two pathway streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial-stages", action="store_true", help="also report every kernel class timed alone on one stream")
     args = ap.parse_args()
 
     from video_classification_amd import dist as sdist
@@ -188,7 +226,12 @@ def main():
     }
     if rank == 0 and not args.no_roofline:
         pl = eng._plan_for(frames, frames, idx, True)
-        stages = instrumented_step(step, pl, frames, labels, idx)
+        # the roofline numbers come from the PRODUCTION schedule (4 lanes); SFK_PER_LAYER additionally dumps the serial view
+        for _ in range(2):
+            stages = instrumented_step(step, pl, frames, labels, idx, "lanes")     # (first pass warms the event pool)
+        if os.environ.get("SFK_PER_LAYER") or args.serial_stages:
+            serial = instrumented_step(step, pl, frames, labels, idx, "serial")
+            line["stages_serial_ms"] = {k_: round(v["ms"], 3) for k_, v in serial.items()}
         rep = {}
         for kind, d in stages.items():
             sec = d["ms"] * 1e-3
@@ -199,6 +242,7 @@ def main():
                 r["algorithmic_GBps"] = round(d["bytes"] / sec / 1e9, 1)
             rep[kind] = r
         line["stages"] = rep
+        line["stages_schedule"] = "production: 4 concurrent lanes, HIP events on each kernel's own stream (kernels of different lanes overlap, so the class times add up to more than ms_per_step)"
         dom = max(stages, key=lambda k: stages[k]["ms"])
         d = stages[dom]
         sec = d["ms"] * 1e-3
@@ -206,9 +250,10 @@ def main():
         # (the conv classes mix 18 MFMA-bound layers with 93 HBM-bound ones; summed, the bytes dominate)
         t_mfma = d["flops"] / (PEAK_MFMA_BF16_TFLOPS * 1e12)
         t_hbm = d["bytes"] / (PEAK_HBM_GBS * 1e9)
-        common = {"avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 1), "launches_per_step": d["launches"],
+        common = {"avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"],
                   "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                   "algorithmic_flops_per_launch": int(d["flops"] / d["launches"]),
+                  "schedule": "production 4-lane step (same as rocprofv3 --kernel-trace of this command: profiles/rNN_class_stats.json)",
                   # sum over launches of max(flops/peak, bytes/peak) / measured time: the per-layer roofline
                   "layerwise_frac": round(d["roof_ms"] / d["ms"], 4),
                   "mfma_frac": round(d["flops"] / sec / 1e12 / PEAK_MFMA_BF16_TFLOPS, 4),
@@ -223,7 +268,18 @@ def main():
                                      "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}, **common)
         line["roofline"]["traffic"], src = pmc_traffic(dom)
         if src:
-            line["roofline"]["traffic_source"] = src
+            line["roofline"]["traffic_source"] = src + " (rocprofv3 --pmc passes over this command; not re-measured in this run)"
+        # chip level: all HBM bytes of a step (PMC) over the step time, against the 8 TB/s spec and the fused-ideal bytes
+        summ, src = pmc_summary()
+        if summ:
+            cls = summ.get("classes", {})
+            # one-off fills / allocations of the first step are excluded: per-step bytes of the recurring kernel classes
+            per_step = sum(c["hbm_bytes_per_step"] for k_, c in cls.items() if k_ != "other")
+            line["chip"] = {"pmc_hbm_bytes_per_step": int(per_step), "pmc_source": src,
+                            "hbm_frac_of_step": round(per_step / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4),
+                            "bytes_vs_fused_ideal": round(per_step / (FUSED_IDEAL_GB_PER_STEP * 1e9), 3),
+                            "fused_ideal_GB_per_step": round(FUSED_IDEAL_GB_PER_STEP, 1),
+                            "note": "bytes from the committed PMC run of this command, ms from THIS run's timed region"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -368,8 +368,11 @@ def assert_k_step_parity(losses, upd, lr, k, loss_rtol=2e-2, min_cos=0.7, med_co
     step count in the bias correction scales every update by up to 3.2x, a missing zero_grad or a stale filter copy
     turns the later updates -- all far outside these bounds."""
     import numpy as np
-    for lo, lm in losses:
-        assert abs(lo - lm) <= loss_rtol * max(abs(lo), 1e-3), losses
+    # step 1 is a pure forward of identical weights; from step 2 on the 2*lr differences of sign-flipped elements feed
+    # back through a loss that moves by O(1) per step on these tiny batches (measured on the GPU: 1e-5, 1e-3, 1e-1)
+    for i, (lo, lm) in enumerate(losses):
+        tol = 1e-4 if i == 0 else (loss_rtol if i == 1 else 0.2)
+        assert abs(lo - lm) <= tol * max(abs(lo), 1e-3), losses
     cosines = sorted(v[0] for v in upd.values())
     assert cosines[0] > min_cos and float(np.median(cosines)) > med_cos, (cosines[:5], float(np.median(cosines)))
     for kk, (cos, ratio, mx) in upd.items():

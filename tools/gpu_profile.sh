@@ -1,12 +1,27 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the bench command (eager launches so every kernel is its own dispatch) + per-layer event timings
+# The round's evidence in one GPU call: default bench line -> rocprofv3 kernel trace of the SAME command (+ per-class
+# summary and the roofline fraction recomputed from the trace) -> optional PMC traffic passes (TRAFFIC=1).
+# Outputs under gpurun_out/; copy what is to be judged into profiles/rNN_*.
 set -u
 mkdir -p gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-SFK_PER_LAYER=gpurun_out/per_layer.json timeout -k 10 600 python bench.py --gpus 1 --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/bench_eager.log 2>&1
-echo "bench eager exit $?"; tail -n 2 gpurun_out/bench_eager.log | cut -c1-400
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --gpus 1 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/rocprof.log 2>&1
-echo "rocprof exit $?"; tail -n 3 gpurun_out/rocprof.log | cut -c1-300
-find gpurun_out/prof -name "*stats*" | head; find gpurun_out/prof -name "*kernel_stats*" -exec head -n 40 {} \;
-# keep the merge small: drop the raw per-dispatch trace if it is big
+STEPS=${STEPS:-10}; WARM=${WARM:-3}
+timeout -k 10 600 python bench.py --gpus 1 --steps $STEPS --warmup $WARM ${BENCH_ARGS:-} > gpurun_out/bench_default.log 2>&1
+rc=$?; echo "bench exit $rc"; tail -n 1 gpurun_out/bench_default.log | cut -c1-600
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
+rm -rf gpurun_out/prof/*
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline > gpurun_out/bench_traced.log 2>&1
+rc=$?; echo "rocprof exit $rc"; tail -n 1 gpurun_out/bench_traced.log | cut -c1-300
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
+KS=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -n 1)
+cp "$KS" gpurun_out/kernel_stats.csv
+# steps the traced command ran: warm-up + timed + 2 instrumented
+python tools/trace_classes.py gpurun_out/kernel_stats.csv $((STEPS+WARM+2)) gpurun_out/bench_traced.log > gpurun_out/class_stats.json
+python - <<'PY'
+import json
+c = json.load(open("gpurun_out/class_stats.json"))
+for k, v in list(c["classes"].items())[:12]: print(f"{k:16s} {v}")
+print(c.get("roofline_check"))
+PY
 find gpurun_out/prof -name "*kernel_trace.csv" -size +40M -delete
+if [ "${TRAFFIC:-0}" = "1" ]; then bash tools/gpu_traffic.sh; fi
