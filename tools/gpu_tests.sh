@@ -1,12 +1,12 @@
 #!/bin/bash
-# All -m gpu tests, one pytest process per file (one at a time), logs under gpurun_out/; a killed step ends the script.
+# All -m gpu tests (K='expr' = pytest -k), one pytest process per file (one at a time), logs under gpurun_out/; a killed step ends the script.
 set -u
 mkdir -p gpurun_out
 : > gpurun_out/tests_summary.log
 FILES=${1:-"tests/test_gpu_kernels.py tests/test_gpu_aux.py tests/test_gpu_dist.py tests/test_gpu_model.py"}
 for f in $FILES; do
   name=$(basename $f .py)
-  timeout -k 10 ${TEST_SECS:-1000} python -m pytest $f -m gpu -q --timeout 900 -p no:cacheprovider -s ${PYTEST_ARGS:-} > gpurun_out/$name.log 2>&1
+  timeout -k 10 ${TEST_SECS:-1000} python -m pytest $f -m gpu -q --timeout 900 -p no:cacheprovider -s ${K:+-k "$K"} > gpurun_out/$name.log 2>&1
   rc=$?
   echo "$name exit $rc: $(tail -n 1 gpurun_out/$name.log)" | tee -a gpurun_out/tests_summary.log
   grep -E "^(FAILED|ERROR)|worst" gpurun_out/$name.log | head -40 | tee -a gpurun_out/tests_summary.log

@@ -24,7 +24,7 @@ def main():
                              "total_ms": round(c["total_ns"] / 1e6, 3), "ms_per_step": round(c["total_ns"] / 1e6 / steps, 3),
                              "avg_us": round(c["total_ns"] / 1e3 / max(c["calls"], 1), 2)}
     if len(sys.argv) > 3:
-        line = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+        line = json.loads([l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1])
         rl = line.get("roofline")
         if rl:
             k = rl["kernel"]
