@@ -362,11 +362,12 @@ def run_k_steps(om, m, x, labels, k, lr, oracle_step=None, device="cpu"):
     return losses, upd
 
 
-def assert_k_step_parity(losses, upd, lr, k, loss_rtol=2e-2, min_cos=0.7, med_cos=0.995):
+def assert_k_step_parity(losses, upd, lr, k, loss_rtol=2e-2, min_cos=0.8, med_cos=0.99):
     """Adam's first update is lr*sign(g): a gradient element whose sign differs (near-zero gradients of a discontinuous
     BN+ReLU+MaxPool net) moves its weight by 2*lr, so the UPDATE is compared by direction and size per tensor.  A wrong
     step count in the bias correction scales every update by up to 3.2x, a missing zero_grad or a stale filter copy
-    turns the later updates -- all far outside these bounds."""
+    turns the later updates -- all far outside these bounds (measured on the GPU, batch 8: worst tensor 0.908, median
+    0.994 at depth 26)."""
     import numpy as np
     # step 1 is a pure forward of identical weights; from step 2 on the 2*lr differences of sign-flipped elements feed
     # back through a loss that moves by O(1) per step on these tiny batches (measured on the GPU: 1e-5, 1e-3, 1e-1)

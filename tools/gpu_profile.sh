@@ -15,8 +15,8 @@ rc=$?; echo "rocprof exit $rc"; tail -n 1 gpurun_out/bench_traced.log | cut -c1-
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 KS=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -n 1)
 cp "$KS" gpurun_out/kernel_stats.csv
-# steps the traced command ran: warm-up + timed + 2 instrumented
-python tools/trace_classes.py gpurun_out/kernel_stats.csv $((STEPS+WARM+2)) gpurun_out/bench_traced.log > gpurun_out/class_stats.json
+# steps the traced command ran: warm-up + timed + 3 instrumented
+python tools/trace_classes.py gpurun_out/kernel_stats.csv $((STEPS+WARM+3)) gpurun_out/bench_traced.log > gpurun_out/class_stats.json
 python - <<'PY'
 import json
 c = json.load(open("gpurun_out/class_stats.json"))
