@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 4
+#define SFK_ABI_VERSION 5
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -100,6 +100,25 @@ typedef struct {
   float* partials;
 } sfk_bn_bwd_fuse;
 
+/* Optional fused output transform of a pass whose rows are the pixels of y in order (os = 1, oo = 0, row extents = y
+ * extents) -- the BatchNorm3d + shortcut + ReLU tail of a bottleneck block (pytorchvideo ResBlock: ReLU(x + norm_c(conv_c(.)))),
+ * computed on the accumulators so that the conv output itself never exists in HBM:
+ *     v = acc * scale[co] + shift[co]          (scale NULL = 1, shift NULL = 0; one of them non-NULL switches this on)
+ *     v += old y                               (when `accumulate`)
+ *     v += res * res_scale[co] + res_shift[co] (res.ptr non-NULL; res_scale NULL = plain residual)
+ *     relu: bits = (v > 0) -> relu_bits (optional, layout of sfk_bn_apply), v = max(v, 0)
+ *     y = v
+ * res / relu / relu_bits need 16-byte channel groups (cout % 8 == 0 in bf16) and cout > 16; scale / shift work everywhere.
+ * Not combinable with stats, bnb or out_relu_bits. */
+typedef struct {
+  const float *scale, *shift;
+  sfk_fmap res; /* ptr == NULL: none */
+  const float *res_scale, *res_shift;
+  int32_t relu;
+  int32_t reserved;
+  uint8_t* relu_bits;
+} sfk_conv_epilogue;
+
 typedef struct {
   sfk_fmap x, y;
   int32_t rt, rh, rw;
@@ -117,12 +136,14 @@ typedef struct {
    * pixel of y in row order (os = 1, oo = 0, row extents = y extents); 8-byte aligned; supported when
    * sfk_conv_relu_out_supported(d). */
   const uint8_t* out_relu_bits;
+  sfk_conv_epilogue ep;
 } sfk_conv_desc;
 
 int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream);
 int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats / d->bnb.partials; <0 on error */
 int sfk_conv_bnb_supported(const sfk_conv_desc* d);  /* 1 if d (ignoring d->bnb) can run with the bnb fusion, else 0 */
 int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out_relu_bits) can apply a bitmap, else 0 */
+int sfk_conv_epilogue_supported(const sfk_conv_desc* d); /* 1 if d's ep (as filled in) can run, else 0 */
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_conv_wgrad -- Conv3d filter gradient (autograd of the same nn.Conv3d modules, train.py:230).
@@ -228,6 +249,40 @@ int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_
 int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                      const float* invstd, const float* scale, const float* shift, int32_t relu,
                      const float* coef, const sfk_fmap* dy, sfk_stream_t stream);
+
+/* dz = da * mask, mask = the ReLU bitmap sfk_bn_apply / sfk_conv_epilogue left (in place when dz aliases da). */
+int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_fmap* dz, sfk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * The block tail  a -> conv_c (1x1x1, bias=False) -> norm_c (BatchNorm3d) [-> + shortcut -> ReLU]  WITHOUT the conv output
+ * in HBM, forward or backward (pytorchvideo bottleneck tail, built via model/my_slowfast.py:94-125; its autograd,
+ * train.py:230).  y = a W^T never has to exist because everything BatchNorm needs from it is a small matrix product:
+ *   with the Gram matrix  G = a^T a  (c x c), the column sums g = 1^T a and the pixel count n
+ *     sum_pix y[co]    = W[co] . g                      sum_pix y[co]^2 = W[co] G W[co]^T
+ *   and, for the backward given dz (gradient at the BatchNorm output after the ReLU mask), R = dz^T a (cout x c), s = 1^T dz:
+ *     sum dz*y[co] = W[co] . R[co];  dy = A dz + B y + C per channel (A = gamma*invstd, B = -A*c2*invstd,
+ *     C = A*(c2*invstd*mean - c1), c1 = s/n, c2 = invstd*(sum dz*y - mean*s)/n), hence
+ *     dW = diag(A) R + diag(B) (W G) + C (x) g,     da = dz (diag(A) W) + a (W^T diag(B) W) + (C W).
+ * The caller keeps `a` with ONE extra channel group whose first channel is the constant 1 (pixel stride ld = c + V,
+ * V = 16 / sizeof(dtype)), so the ordinary filter-gradient kernel delivers everything in two calls:
+ *     gram = sfk_conv_wgrad(x = a[0 : c+V), dy = a[0 : c+V))  -> [c+V][c+V]: G, row c = g, element (c, c) = n
+ *     rx   = sfk_conv_wgrad(x = a[0 : c+V), dy = dz)          -> [cout][c+V]: R, column c = s
+ * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift exactly as sfk_bn_finalize, from `gram`; also
+ *   leaves t = W G ([cout][c] fp32) for the backward.  w = the conv's filter [cout][c] in compute precision (w_dtype).
+ * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the two data-gradient passes
+ *     wd [c][cout] (w_dtype) = (A W)^T      -> pass 1: da  = dz . wd          (sfk_conv_igemm, plain)
+ *     ws [cout][c] (w_dtype) = diag(B) W    -> m32 = sfk_conv_wgrad(x = W as a [cout pixels][c] map, dy = ws) = W^T diag(B) W;
+ *                                              cast to w_dtype -> pass 2: da += a . m + bias   (accumulate + ep.shift)
+ *     bias [c] fp32 = C W
+ */
+int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
+                    float* shift, float* t, sfk_stream_t stream);
+int sfk_bn_tail_bwd(const float* rx, const float* gram, const float* t, int32_t c, int32_t gld, const void* w,
+                    int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
+                    float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
+                    sfk_stream_t stream); /* coef: [cout][4] fp32 scratch */
 
 /* ---------------------------------------------------------------------------------------------------------
  * MaxPool3d (1,k,k)/(1,s,s)/(0,p,p) of the stems (my_slowfast.py:66-68).  `argmax` (uint8 per output

@@ -77,6 +77,31 @@ class EmuBackend:
             Y = p.y.view5()
             sl = tuple(slice(o, o + (r - 1) * s + 1, s) for o, s, r in zip(p.oo, p.os, p.rows))
             dest = Y[:, sl[0], sl[1], sl[2]]
+            ep = getattr(p, "ep", None)
+            if ep is not None:                    # sfk_conv_epilogue: scale / shift, (+ old), shortcut, ReLU (+ bitmap)
+                v = acc
+                if ep.scale is not None:
+                    v = v * ep.scale[: p.cout].float()
+                if ep.shift is not None:
+                    v = v + ep.shift[: p.cout].float()
+                if p.accumulate:
+                    v = v + dest.float()
+                if ep.res is not None:
+                    r = ep.res.view5().float()
+                    if ep.res_scale is not None:
+                        r = r * ep.res_scale[: p.cout].float()
+                    if ep.res_shift is not None:
+                        r = r + ep.res_shift[: p.cout].float()
+                    v = v + r
+                if ep.relu:
+                    if ep.relu_bits is not None:
+                        vec = 8 if Y.dtype == torch.bfloat16 else 4
+                        m = (v > 0).reshape(-1, p.cout // vec, vec).to(torch.int32)
+                        packed = (m << torch.arange(vec, dtype=torch.int32)).sum(-1).to(torch.uint8)
+                        ep.relu_bits[: packed.numel()].copy_(packed.reshape(-1))
+                    v = torch.relu(v)
+                dest.copy_(v.to(Y.dtype))
+                return
             res = dest.float() + acc if p.accumulate else acc
             if p.relu_out_bits is not None:       # Y is the gradient w.r.t. a ReLU output: store result * mask
                 vec = 8 if Y.dtype == torch.bfloat16 else 4
@@ -103,6 +128,63 @@ class EmuBackend:
 
     def conv_relu_out_supported(self, p) -> bool:
         return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
+
+    def conv_epilogue_supported(self, p) -> bool:
+        return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
+
+    # ------------------------------------------------------------------ bottleneck tail (sfk_bn_tail_*, sfk_relu_bits_mask)
+    def relu_bits_mask(self, da: FMap, relu_bits, dz: FMap):
+        def run(stream):
+            vec = self._vec(da)
+            b = relu_bits[: da.pixels * (da.c // vec)].to(torch.int32).reshape(-1, da.c // vec, 1)
+            m = ((b >> torch.arange(vec, dtype=torch.int32)) & 1).reshape(da.n, da.t, da.h, da.w, da.c)
+            dz.view5().copy_((da.view5().float() * m.float()).to(dz.dtype))
+        return run
+
+    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, t):
+        def run(stream):
+            Gx = gram[: gld * gld].view(gld, gld).double()
+            G, g, n = Gx[:c, :c], Gx[c, :c], float(Gx[c, c])
+            W = w[: cout * c].view(cout, c).double()
+            T = W @ G
+            t[: cout * c].copy_(T.float().reshape(-1))
+            mu = (W @ g) / n
+            var = ((T * W).sum(1) / n - mu * mu).clamp_min(0.0)
+            is_ = 1.0 / torch.sqrt(var + eps)
+            mean[:cout].copy_(mu.float())
+            invstd[:cout].copy_(is_.float())
+            sc = gamma[:cout].double() * is_
+            scale[:cout].copy_(sc.float())
+            shift[:cout].copy_((beta[:cout].double() - mu * sc).float())
+            if rm is not None:
+                unb = var * n / (n - 1.0) if n > 1 else var
+                rm[:cout].mul_(1 - momentum).add_(momentum * mu.float())
+                rv[:cout].mul_(1 - momentum).add_(momentum * unb.float())
+            if nbt is not None:
+                nbt.add_(1)
+        return run
+
+    def bn_tail_bwd(self, rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
+        def run(stream):
+            Rx = rx[: cout * gld].view(cout, gld).double()
+            R, s_ = Rx[:, :c], Rx[:, c]
+            Gx = gram[: gld * gld].view(gld, gld).double()
+            g, n = Gx[c, :c], float(Gx[c, c])
+            W = w[: cout * c].view(cout, c).double()
+            T = t[: cout * c].view(cout, c).double()
+            is_, mu = invstd[:cout].double(), mean[:cout].double()
+            sxh = is_ * ((W * R).sum(1) - mu * s_)
+            dgamma[:cout].add_(sxh.float())
+            dbeta[:cout].add_(s_.float())
+            A = gamma[:cout].double() * is_
+            c1, c2 = s_ / n, sxh / n
+            B = -A * c2 * is_
+            Cc = A * (c2 * is_ * mu - c1)
+            dw[: cout * c].add_((A[:, None] * R + B[:, None] * T + Cc[:, None] * g[None, :]).float().reshape(-1))
+            wd[: cout * c].copy_((A[:, None] * W).t().contiguous().reshape(-1).to(wd.dtype))
+            ws[: cout * c].copy_((B[:, None] * W).reshape(-1).to(ws.dtype))
+            bias[:c].copy_((Cc @ W).float())
+        return run
 
     def conv_wgrad(self, p: WgradPass):
         def run(stream):

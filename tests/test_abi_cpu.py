@@ -38,7 +38,7 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(_lib._FMap) == 40            # void* + 8 x int32
     assert ctypes.sizeof(_lib._Tap) == 4
     assert _lib._ConvDesc.taps.size == 4 * _lib.SFK_MAX_TAPS
-    assert lib.sfk_abi_version() == 4
+    assert lib.sfk_abi_version() == 5
     assert lib.sfk_status_string(0) == b"ok" and lib.sfk_status_string(-2).startswith(b"unsupported")
 
 
@@ -81,7 +81,7 @@ def test_integration_md_stub_matches_the_abi(lib):
     from video_classification_amd import _lib
     ns = _integration_stub_structs()
     for doc_name, ours in (("FMap", _lib._FMap), ("Tap", _lib._Tap), ("BnBwdFuse", _lib._BnBwdFuse),
-                           ("ConvDesc", _lib._ConvDesc)):
+                           ("ConvEpilogue", _lib._ConvEpilogue), ("ConvDesc", _lib._ConvDesc)):
         doc = ns[doc_name]
         assert [f[0] for f in doc._fields_] == [f[0] for f in ours._fields_], doc_name
         assert ctypes.sizeof(doc) == ctypes.sizeof(ours), doc_name
@@ -94,7 +94,7 @@ def test_header_struct_sizes_match_ctypes(lib, tmp_path):
     import subprocess
     from video_classification_amd import _lib
     names = {"sfk_fmap": _lib._FMap, "sfk_tap": _lib._Tap, "sfk_bn_bwd_fuse": _lib._BnBwdFuse,
-             "sfk_conv_desc": _lib._ConvDesc, "sfk_wgrad_desc": _lib._WgradDesc, "sfk_stem_src": _lib._StemSrc,
+             "sfk_conv_epilogue": _lib._ConvEpilogue, "sfk_conv_desc": _lib._ConvDesc, "sfk_wgrad_desc": _lib._WgradDesc, "sfk_stem_src": _lib._StemSrc,
              "sfk_tuning": _lib._Tuning}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "sfk.h"\nint main(void){' +

@@ -625,3 +625,79 @@ def test_conv_operand_beyond_2gib_runs_register_staged(hip):
     y_ref = torch.cat([p_[0] for p_ in parts])
     assert rel_err(y_all.float().cpu(), y_ref.float().cpu()) < 1e-2 and float(y_ref.float().abs().max()) > 1.0
     assert rel_err(st_all.cpu(), (parts[0][1] + parts[1][1]).cpu()) < 1e-4
+
+
+# ------------------------------------------------------------------ the bottleneck tail without the conv output in HBM
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 2, 9, 10, 8, 32), (2, 3, 7, 7, 16, 64), (1, 2, 14, 14, 64, 256), (2, 2, 7, 7, 512, 2048),
+                                   (1, 4, 28, 28, 128, 512)],
+                         ids=["fast-res2", "fast-res3", "slow-res2", "slow-res5", "slow-res3-dma"])
+def test_bottleneck_tail_forward_backward(hip, dtype, shape):
+    """sfk_conv_epilogue + sfk_bn_tail_fwd/bwd + sfk_relu_bits_mask + the two sfk_conv_wgrad / sfk_conv_igemm calls around
+    them: the call sequence of tests/test_tail_cpu.py on the GPU -- against the same sequence on the CPU restatement
+    (same precision) and, in fp32, against torch autograd of conv -> BatchNorm3d -> + shortcut -> ReLU."""
+    from test_tail_cpu import make_case, run_tail, tail_reference
+    n, t, h, w, c, cout = shape
+    case = make_case(n, t, h, w, c, cout, seed=c + cout)
+    if dtype == torch.bfloat16:            # both sides start from the same bf16-representable operands
+        case = tuple(x.to(torch.bfloat16).double() for x in case)
+    got = run_tail(hip, DEV, dtype, *case, stream=stream())
+    emu = run_tail(EmuBackend(), "cpu", dtype, *case)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    for k in ("out", "mean", "var", "rm", "rv", "dz", "dW", "dgamma", "dbeta", "da", "m32", "bias"):
+        assert rel_err(got[k], emu[k]) < (tol if k not in ("var", "rv") else 10 * tol), (k, rel_err(got[k], emu[k]))
+    assert got["nbt"] == 1
+    if dtype == torch.float32:
+        ref = tail_reference(*case)
+        assert rel_err(got["out"], ref["out"].float()) < 1e-4
+        for k in ("dgamma", "dbeta", "dW", "da"):
+            assert rel_err(got[k], ref[k].float()) < 5e-4, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_epilogue_variants(hip, dtype):
+    """sfk_conv_epilogue on a 3x3 conv and on narrow outputs: scale/shift only, += with a bias, ReLU without a shortcut,
+    a shortcut living in a channel slice of a wider record"""
+    from video_classification_amd._lib import ConvEpilogue
+    gen = torch.Generator().manual_seed(21)
+    emu = EmuBackend()
+    n, t, h, w = 2, 2, 9, 7
+    for cin, cout, k3 in ((16, 8, False), (8, 16, True), (32, 40, True), (24, 136, False)):
+        g = ConvGeom(cin, cout, (1, 3, 3) if k3 else (1, 1, 1), (1, 1, 1), (0, 1, 1) if k3 else (0, 0, 0))
+        sp = fwd_pass(g, (t, h, w))
+        xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen)
+        wt = mk((cout * g.wtaps * cin,), dtype, gen, 0.2)
+        sc, sh = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+        rs, rh = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+        wide_ok = cout > 16
+        variants = [dict(scale=True, shift=True), dict(shift=True, accumulate=True)]
+        if wide_ok:
+            variants += [dict(scale=True, shift=True, relu=True, bits=True), dict(scale=True, shift=True, res=True, relu=True, bits=True),
+                         dict(shift=True, res=True, res_affine=True, relu=True)]
+        for v in variants:
+            yc, yg = fmap_pair(n, cout, t, h, w, dtype, gen, ld=cout + 8, c_off=8)
+            rc, rg = fmap_pair(n, cout, t, h, w, dtype, gen, ld=cout + 16, c_off=16)
+            vec = 8 if dtype == torch.bfloat16 else 4
+            outs = []
+            for be, x, y, r, dev, st in ((emu, xc, yc, rc, "cpu", 0), (hip, xg, yg, rg, DEV, stream())):
+                bits = torch.zeros(y.pixels * (cout // vec), dtype=torch.uint8, device=dev) if v.get("bits") else None
+                ep = ConvEpilogue(scale=sc.to(dev) if v.get("scale") else None, shift=sh.to(dev) if v.get("shift") else None,
+                                  res=r if v.get("res") else None, relu=bool(v.get("relu")), relu_bits=bits)
+                if v.get("res_affine"):
+                    ep.res_scale, ep.res_shift = rs.to(dev), rh.to(dev)
+                p = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(dev), g.wtaps, cin, cout,
+                             accumulate=bool(v.get("accumulate")), ep=ep)
+                assert be.conv_epilogue_supported(p)
+                be.conv_igemm(p)(st)
+                outs.append((y, bits))
+            torch.cuda.synchronize()
+            (yc_, bc), (yg_, bg) = outs
+            assert rel_err(yg_.buf.float().cpu(), yc_.buf.float()) < TOL[dtype], (cin, cout, k3, v)
+            if bc is not None:      # bits may differ only where the pre-activation is within rounding of zero
+                assert float((bg.cpu() != bc).float().mean()) < (2e-3 if dtype == torch.float32 else 3e-2)
+    # unsupported combinations are rejected on the host
+    xc, xg = fmap_pair(1, 8, 1, 4, 4, torch.bfloat16, gen)
+    yc, yg = fmap_pair(1, 8, 1, 4, 4, torch.bfloat16, gen)
+    p = ConvPass(xg, yg, (1, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0), [(0, 0, 0, 0)], torch.zeros(64, dtype=torch.bfloat16, device=DEV),
+                 1, 8, 8, ep=ConvEpilogue(shift=torch.zeros(8, device=DEV), relu=True))
+    assert not hip.conv_epilogue_supported(p)            # ReLU needs two co fragments per wave in bf16 (cout > 16)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 4        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 5        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -85,6 +85,18 @@ class BnBwdFuse:
 
 
 @dataclass
+class ConvEpilogue:
+    """sfk_conv_epilogue: v = acc*scale + shift (+ old y) (+ res*res_scale + res_shift); ReLU (+ bitmap); y = v."""
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    res: Optional[FMap] = None
+    res_scale: Optional[torch.Tensor] = None
+    res_shift: Optional[torch.Tensor] = None
+    relu: bool = False
+    relu_bits: Optional[torch.Tensor] = None
+
+
+@dataclass
 class ConvPass:
     x: FMap
     y: FMap
@@ -101,6 +113,7 @@ class ConvPass:
     stats: Optional[torch.Tensor] = None  # fp32 [mtiles][cout][2]
     bnb: Optional[BnBwdFuse] = None
     relu_out_bits: Optional[torch.Tensor] = None   # uint8 bitmap of bn_apply: the pass stores result * mask
+    ep: Optional[ConvEpilogue] = None
 
 
 @dataclass
@@ -147,12 +160,17 @@ class _BnBwdFuse(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int32), ("partials", C.c_void_p)]
 
 
+class _ConvEpilogue(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("res", _FMap), ("res_scale", C.c_void_p),
+                ("res_shift", C.c_void_p), ("relu", C.c_int32), ("reserved", C.c_int32), ("relu_bits", C.c_void_p)]
+
+
 class _ConvDesc(C.Structure):
     _fields_ = [("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
                 ("gs", C.c_int32 * 3), ("os", C.c_int32 * 3), ("oo", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("w", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("bnb", _BnBwdFuse),
-                ("out_relu_bits", C.c_void_p)]
+                ("out_relu_bits", C.c_void_p), ("ep", _ConvEpilogue)]
 
 
 class _WgradDesc(C.Structure):
@@ -193,6 +211,10 @@ SIGNATURES = {
     "sfk_conv_igemm_mtiles": [C.POINTER(_ConvDesc)],
     "sfk_conv_bnb_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
+    "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
+    "sfk_relu_bits_mask": [_P_FMAP, _PV, _P_FMAP, _PV],
+    "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
+    "sfk_bn_tail_bwd": [_PF, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
@@ -318,6 +340,18 @@ def _c_conv(p: ConvPass) -> _ConvDesc:
         vec = 8 if p.y.dtype == torch.bfloat16 else 4
         assert p.relu_out_bits.dtype == torch.uint8 and p.relu_out_bits.numel() >= p.y.pixels * (p.cout // vec)
         d.out_relu_bits = p.relu_out_bits.data_ptr()
+    if p.ep is not None:
+        e = p.ep
+        assert e.scale is not None or e.shift is not None
+        d.ep.scale, d.ep.shift = _ptr(e.scale), _ptr(e.shift)
+        if e.res is not None:
+            d.ep.res = _c_fmap(e.res)
+        d.ep.res_scale, d.ep.res_shift = _ptr(e.res_scale), _ptr(e.res_shift)
+        d.ep.relu = 1 if e.relu else 0
+        if e.relu_bits is not None:
+            vec = 8 if p.y.dtype == torch.bfloat16 else 4
+            assert e.relu_bits.dtype == torch.uint8 and e.relu_bits.numel() >= p.y.pixels * (p.cout // vec)
+            d.ep.relu_bits = e.relu_bits.data_ptr()
     return d
 
 
@@ -346,6 +380,10 @@ class HipBackend:
         """can this pass apply a ReLU bitmap to what it stores (sfk_conv_relu_out_supported)?"""
         q = ConvPass(**{**p.__dict__, "relu_out_bits": None})
         return bool(self.lib.sfk_conv_relu_out_supported(C.byref(_c_conv(q))))
+
+    def conv_epilogue_supported(self, p: ConvPass) -> bool:
+        """can this pass run with its fused output transform p.ep (sfk_conv_epilogue_supported)?"""
+        return bool(self.lib.sfk_conv_epilogue_supported(C.byref(_c_conv(p))))
 
     def conv_igemm(self, p: ConvPass):
         d, fn, keep = _c_conv(p), self.lib.sfk_conv_igemm, p
@@ -498,6 +536,24 @@ class HipBackend:
         return self._plain("sfk_bn_bwd_apply", C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean),
                            _ptr(invstd), _ptr(scale), _ptr(shift), 1 if relu else 0, _ptr(coef), C.byref(fo),
                            keep=(fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift, coef))
+
+    # -- the bottleneck tail (conv_c -> norm_c without the conv output in HBM)
+    def relu_bits_mask(self, da: FMap, relu_bits, dz: FMap):
+        fa, fz = _c_fmap(da), _c_fmap(dz)
+        return self._plain("sfk_relu_bits_mask", C.byref(fa), _ptr(relu_bits), C.byref(fz), keep=(fa, fz, da, dz, relu_bits))
+
+    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
+                    scale, shift, t):
+        ts = (gram, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t)
+        return self._plain("sfk_bn_tail_fwd", _ptr(gram), c, gld, _ptr(w), _DT[w.dtype], cout, _ptr(gamma), _ptr(beta), eps,
+                           momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
+                           _ptr(scale), _ptr(shift), _ptr(t), keep=ts)
+
+    def bn_tail_bwd(self, rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
+        ts = (rx, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
+        return self._plain("sfk_bn_tail_bwd", _ptr(rx), _ptr(gram), _ptr(t), c, gld, _ptr(w), _DT[w.dtype], cout, _ptr(gamma),
+                           _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(wd), _ptr(ws), _ptr(bias),
+                           _ptr(coef), keep=ts)
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

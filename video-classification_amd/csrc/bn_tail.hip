@@ -1,0 +1,259 @@
+// The bottleneck tail  a -> conv_c (1x1x1) -> norm_c [-> + shortcut -> ReLU]  without the conv output in HBM
+// (include/sfk.h, sfk_bn_tail_fwd / sfk_bn_tail_bwd): the small per-layer algebra between the big kernels.
+//
+// What the big kernels deliver (ordinary sfk_conv_wgrad calls over `a` widened by a constant-1 channel):
+//     gram [c+V][c+V] fp32 : G = a^T a, row c = column sums g, element (c,c) = pixel count n
+//     rx   [cout][c+V] fp32: R = dz^T a, column c = s = sum dz
+// What this file computes from them -- everything is O(cout * c^2) or less, i.e. independent of the pixel count:
+//     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift
+//     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the two data-gradient passes
+//               wd = (diag(A) W)^T, ws = diag(B) W (its Gram-like product W^T ws is one more sfk_conv_wgrad call), bias = C W
+// Sums over channels / rows run in double and in a fixed order: deterministic, no atomics.
+#include "sfk_common.h"
+
+namespace {
+
+template <typename D> __device__ __forceinline__ float wload(const void* w, int64_t i) {
+  return (float)static_cast<const D*>(w)[i];
+}
+
+constexpr int TF_CO = 8;      // output channels per block of the forward kernel
+constexpr int TF_MAXC = 512;  // widest conv_c input of the ResNet-50/101/152 SlowFast family (2048 / 4)
+
+// T[co][:] = W[co][:] G,  m1 = W[co] . g / n,  m2 = T[co] . W[co] / n  for TF_CO channels per block; thread <-> column ci
+template <typename D>
+__global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restrict__ gram, int c, int gld, const void* w,
+                                                          int cout, const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          int64_t* nbt, float* mean, float* invstd, float* scale,
+                                                          float* shift, float* __restrict__ t) {
+  __shared__ float wl[TF_CO][TF_MAXC];
+  __shared__ double red[256][2];
+  const int co0 = blockIdx.x * TF_CO, tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0 && nbt) nbt[0] += 1;
+  for (int i = tid; i < TF_CO * c; i += 256) {
+    const int o = i / c, j = i % c;
+    wl[o][j] = co0 + o < cout ? wload<D>(w, (int64_t)(co0 + o) * c + j) : 0.f;
+  }
+  __syncthreads();
+  constexpr int NR = TF_MAXC / 256;
+  float acc[TF_CO][NR];
+#pragma unroll
+  for (int o = 0; o < TF_CO; ++o)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[o][r] = 0.f;
+  for (int j = 0; j < c; ++j) {
+    float gj[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ci = tid + 256 * r;
+      gj[r] = ci < c ? gram[(int64_t)j * gld + ci] : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < TF_CO; ++o) {
+      const float wv = wl[o][j];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[o][r] += wv * gj[r];
+    }
+  }
+  const double n = (double)gram[(int64_t)c * gld + c];
+  for (int o = 0; o < TF_CO; ++o) {            // (uniform trip count: the barriers inside are reached by every thread)
+    double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ci = tid + 256 * r;
+      if (ci < c) {
+        if (co0 + o < cout) t[(int64_t)(co0 + o) * c + ci] = acc[o][r];
+        p1 += (double)wl[o][ci] * (double)gram[(int64_t)c * gld + ci];
+        p2 += (double)acc[o][r] * (double)wl[o][ci];
+      }
+    }
+    red[tid][0] = p1;
+    red[tid][1] = p2;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {   // fixed tree: deterministic
+      if (tid < sft) {
+        red[tid][0] += red[tid + sft][0];
+        red[tid][1] += red[tid + sft][1];
+      }
+      __syncthreads();
+    }
+    if (tid == 0 && co0 + o < cout) {
+      const int ch = co0 + o;
+      const double mu = red[0][0] / n;
+      double var = red[0][1] / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[ch] * is;
+      mean[ch] = (float)mu;
+      invstd[ch] = is;
+      scale[ch] = sc;
+      shift[ch] = beta[ch] - (float)mu * sc;
+      if (running_mean) {
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one wave per output channel: sum dz*y = W[co] . R[co]; coefficients of dy = A dz + B y + C; dgamma, dbeta
+template <typename D>
+__global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ gram,
+                                                           int c, int gld, const void* w, int cout, const float* gamma,
+                                                           const float* mean, const float* invstd, float* dgamma,
+                                                           float* dbeta, float* coef) {
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (co >= cout) return;
+  double sdy = 0.0;
+  for (int ci = lane; ci < c; ci += 64) sdy += (double)wload<D>(w, (int64_t)co * c + ci) * (double)rx[(int64_t)co * gld + ci];
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) sdy += __shfl_xor(sdy, sft);
+  if (lane != 0) return;
+  const double n = (double)gram[(int64_t)c * gld + c];
+  const double s = (double)rx[(int64_t)co * gld + c];
+  const double is = (double)invstd[co], mu = (double)mean[co];
+  const double sxh = is * (sdy - mu * s);                 // sum dz * x_hat
+  dgamma[co] += (float)sxh;
+  dbeta[co] += (float)s;
+  const double A = (double)gamma[co] * is, c1 = s / n, c2 = sxh / n;
+  coef[co * 4 + 0] = (float)A;
+  coef[co * 4 + 1] = (float)(-A * c2 * is);               // B
+  coef[co * 4 + 2] = (float)(A * (c2 * is * mu - c1));    // C
+  coef[co * 4 + 3] = 0.f;
+}
+
+// 32 x 32 (co, ci) tiles: dW += A R + B T + C g;  ws = B W;  wd = (A W)^T through LDS (coalesced both ways)
+template <typename D>
+__global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restrict__ rx, const float* __restrict__ gram,
+                                                            const float* __restrict__ t, int c, int gld, const void* w,
+                                                            int cout, const float* __restrict__ coef, float* dw, D* wd,
+                                                            D* ws) {
+  __shared__ float tile[32][33];
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + ty + 8 * i, ci = ci0 + tx;
+    float aw = 0.f;
+    if (co < cout && ci < c) {
+      const float A = coef[co * 4], B = coef[co * 4 + 1], Cc = coef[co * 4 + 2];
+      const int64_t idx = (int64_t)co * c + ci;
+      const float wv = wload<D>(w, idx);
+      dw[idx] += A * rx[(int64_t)co * gld + ci] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
+      ws[idx] = (D)(B * wv);
+      aw = A * wv;
+    }
+    tile[ty + 8 * i][tx] = aw;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ci = ci0 + ty + 8 * i, co = co0 + tx;
+    if (co < cout && ci < c) wd[(int64_t)ci * cout + co] = (D)tile[tx][ty + 8 * i];
+  }
+}
+
+// bias[ci] = sum_co C[co] W[co][ci]: 64 columns x 4 row partitions per block
+template <typename D>
+__global__ __launch_bounds__(256) void bn_tail_bias_kernel(const void* w, int c, int cout, const float* __restrict__ coef,
+                                                           float* bias) {
+  __shared__ double red[4][64];
+  const int ci = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s = 0.0;
+  if (ci < c)
+    for (int co = part; co < cout; co += 4) s += (double)coef[co * 4 + 2] * (double)wload<D>(w, (int64_t)co * c + ci);
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && ci < c) bias[ci] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dz = da * mask(bitmap): 16 bytes per thread, one bitmap byte each
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bits_mask_kernel(const T* da, int dld, int doff, T* dz, int zld, int zoff,
+                                                             const uint8_t* __restrict__ bits, int64_t groups, int cgs) {
+  constexpr int VEC = DT<T>::VEC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < groups; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cgs;
+    const int cg = (int)(i - p * cgs);
+    Vec16<T> v;
+    v.load(da + p * dld + doff + cg * VEC);
+    const uint32_t b = bits[i];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      if (!((b >> e) & 1u)) v.set(e, 0.f);
+    v.store(dz + p * zld + zoff + cg * VEC);
+  }
+}
+
+inline bool tail_args_ok(int c, int gld, int cout, int dtype) {
+  return c > 0 && cout > 0 && gld > c && (dtype == SFK_F32 || dtype == SFK_BF16);
+}
+
+}  // namespace
+
+extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale, float* shift,
+                               float* t, sfk_stream_t stream) {
+  if (!gram || !w || !gamma || !beta || !mean || !invstd || !scale || !shift || !t) return SFK_ERR_INVALID;
+  if (!tail_args_ok(c, gld, cout, w_dtype) || (!running_mean) != (!running_var)) return SFK_ERR_INVALID;
+  if (c > TF_MAXC) return SFK_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((cout + TF_CO - 1) / TF_CO), blk(256);
+  if (w_dtype == SFK_BF16)
+    hipLaunchKernelGGL(bn_tail_fwd_kernel<bf16_t>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
+                       running_mean, running_var, nbt, mean, invstd, scale, shift, t);
+  else
+    hipLaunchKernelGGL(bn_tail_fwd_kernel<float>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
+                       running_mean, running_var, nbt, mean, invstd, scale, shift, t);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+template <typename D>
+static int tail_bwd_launch(const float* rx, const float* gram, const float* t, int c, int gld, const void* w, int cout,
+                           const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                           float* dw, void* wd, void* ws, float* bias, float* coef, hipStream_t s) {
+  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, gram, c, gld, w, cout, gamma, mean,
+                     invstd, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_tail_apply_kernel<D>, dim3((c + 31) / 32, (cout + 31) / 32), dim3(256), 0, s, rx, gram, t, c, gld,
+                     w, cout, coef, dw, static_cast<D*>(wd), static_cast<D*>(ws));
+  hipLaunchKernelGGL(bn_tail_bias_kernel<D>, dim3((c + 63) / 64), dim3(256), 0, s, w, c, cout, coef, bias);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+extern "C" int sfk_bn_tail_bwd(const float* rx, const float* gram, const float* t, int32_t c, int32_t gld, const void* w,
+                               int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
+                               float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
+                               sfk_stream_t stream) {
+  if (!rx || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
+    return SFK_ERR_INVALID;
+  if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return w_dtype == SFK_BF16
+             ? tail_bwd_launch<bf16_t>(rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
+             : tail_bwd_launch<float>(rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
+}
+
+extern "C" int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_fmap* dz, sfk_stream_t stream) {
+  if (!sfk_fmap_ok(da) || !sfk_fmap_ok(dz) || !relu_bits) return SFK_ERR_INVALID;
+  if (da->dtype != dz->dtype || da->c != dz->c || sfk_fmap_pixels(da) != sfk_fmap_pixels(dz)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(da) || !sfk_fmap_vec_ok(dz)) return SFK_ERR_UNSUPPORTED;
+  const int vec = sfk_vec_of(da->dtype), cgs = da->c / vec;
+  const int64_t groups = sfk_fmap_pixels(da) * cgs;
+  int64_t blocks = (groups + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (da->dtype == SFK_BF16)
+    hipLaunchKernelGGL(relu_bits_mask_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const bf16_t*>(da->ptr),
+                       da->ld, da->c_off, static_cast<bf16_t*>(dz->ptr), dz->ld, dz->c_off, relu_bits, groups, cgs);
+  else
+    hipLaunchKernelGGL(relu_bits_mask_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(da->ptr),
+                       da->ld, da->c_off, static_cast<float*>(dz->ptr), dz->ld, dz->c_off, relu_bits, groups, cgs);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}

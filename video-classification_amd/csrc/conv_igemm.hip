@@ -37,6 +37,11 @@ struct ConvK {
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_parts;         // [mtiles][cout][2] = (sum dz, sum dz * x_hat) per row tile; NULL = fusion off
   const uint8_t* obits;    // ReLU bitmap applied to the stored result (sfk_conv_desc.out_relu_bits), or NULL
+  // fused output transform (sfk_conv_desc.ep): v = acc*scale + shift (+ old) (+ res*rscale + rshift), ReLU (+ bitmap)
+  const float *ep_scale, *ep_shift, *ep_rscale, *ep_rshift;
+  const void* ep_res;
+  int ep_rld, ep_roff, ep_relu, ep_on;
+  uint8_t* ep_bits;
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
@@ -264,6 +269,128 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
   }
 }
 
+// Fused output transform (EPI == 3, sfk_conv_epilogue): BatchNorm scale / shift, shortcut, ReLU and its bitmap on the
+// accumulators -- the conv output of a bottleneck's conv_c never reaches HBM; also the "+ bias" of the second
+// data-gradient pass of that tail.  Rows are the output pixels (lin_out).  All loads of a fragment row group (old values,
+// shortcut) are issued before the first store (a load behind a store waits out a round trip: see load8_old).
+template <typename T, int FM, int FN, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc)[FN][FM], int mt, int nt, int wm, int wn,
+                                               int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  T* __restrict__ yp = static_cast<T*>(k.y);
+  const T* __restrict__ rp = static_cast<const T*>(k.ep_res);
+  const int co_w = nt * BN + wn * (BN / WN);
+  int64_t rows[FM];
+  bool rok[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    rok[j] = m < k.M;
+    rows[j] = rok[j] ? m : k.M - 1;          // rows past M re-read the last row (branch-free loads), nothing is stored
+  }
+  if constexpr (sizeof(T) == 2 && (FN % 2) == 0) {
+    // bf16, 16-byte channel groups: fragment pairs, 8 consecutive channels per lane after the permlane swap
+#pragma unroll
+    for (int p = 0; p < FN; p += 2) {
+      const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
+      const bool cok = co < k.cout;
+      const int cc = cok ? co : 0;
+      float sc[8], sh[8], rs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = k.ep_scale ? k.ep_scale[cc + e] : 1.f;
+        sh[e] = (k.ep_shift ? k.ep_shift[cc + e] : 0.f) + ((rp && k.ep_rshift) ? k.ep_rshift[cc + e] : 0.f);
+        rs[e] = (rp && k.ep_rscale) ? k.ep_rscale[cc + e] : 1.f;
+      }
+      // two pixel rows at a time: the 256x128 tile sits at its 128-VGPR cap, 2 x (old, shortcut) x 16 B is what fits
+      constexpr int JB = FM >= 2 ? 2 : 1;
+#pragma unroll
+      for (int j0 = 0; j0 < FM; j0 += JB) {
+        bf16x8 oldv[JB], resv[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const int j = j0 + jj;
+          if (k.accumulate) oldv[jj] = *reinterpret_cast<const bf16x8*>(yp + rows[j] * k.yld + k.yoff + cc);
+          if (rp) resv[jj] = *reinterpret_cast<const bf16x8*>(rp + rows[j] * k.ep_rld + k.ep_roff + cc);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const int j = j0 + jj;
+          float v[8] = {acc[p][j][0], acc[p][j][1], acc[p][j][2], acc[p][j][3],
+                        acc[p + 1][j][0], acc[p + 1][j][1], acc[p + 1][j][2], acc[p + 1][j][3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
+          if (!rok[j] || !cok) continue;
+          uint32_t bits = 0;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = v[e] * sc[e] + sh[e];
+            if (k.accumulate) f += (float)oldv[jj][e];
+            if (rp) f += (float)resv[jj][e] * rs[e];
+            if (k.ep_relu) {
+              bits |= (f > 0.f ? 1u : 0u) << e;
+              f = f > 0.f ? f : 0.f;
+            }
+            o[e] = (bf16_t)f;
+          }
+          *reinterpret_cast<bf16x8*>(yp + rows[j] * k.yld + k.yoff + co) = o;
+          if (k.ep_bits) k.ep_bits[rows[j] * (k.cout >> 3) + (co >> 3)] = (uint8_t)bits;
+        }
+      }
+    }
+  } else {
+    // f32 (16-byte groups of 4 channels), and bf16 tiles with one co fragment (scale / shift / += only there)
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int co = co_w + 16 * i + 4 * g;
+      const bool cok = co < k.cout;
+      const int cc = cok ? co : 0;
+      float sc[4], sh[4], rs[4], rh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = k.ep_scale ? k.ep_scale[cc + e] : 1.f;
+        sh[e] = k.ep_shift ? k.ep_shift[cc + e] : 0.f;
+        rs[e] = (rp && k.ep_rscale) ? k.ep_rscale[cc + e] : 1.f;
+        rh[e] = (rp && k.ep_rshift) ? k.ep_rshift[cc + e] : 0.f;
+      }
+      float oldv[FM][4], resv[FM][4];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          oldv[j][e] = k.accumulate ? (float)yp[rows[j] * k.yld + k.yoff + cc + e] : 0.f;
+          resv[j][e] = rp ? (float)rp[rows[j] * k.ep_rld + k.ep_roff + cc + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if (!rok[j] || !cok) continue;
+        uint32_t bits = 0;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = acc[i][j][e] * sc[e] + sh[e] + oldv[j][e];
+          if (rp) f[e] += resv[j][e] * rs[e] + rh[e];
+          if (k.ep_relu) {
+            bits |= (f[e] > 0.f ? 1u : 0u) << e;
+            f[e] = f[e] > 0.f ? f[e] : 0.f;
+          }
+        }
+        T* op = yp + rows[j] * k.yld + k.yoff + co;
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(op) = make_float4(f[0], f[1], f[2], f[3]);
+          if (k.ep_bits) k.ep_bits[rows[j] * (k.cout >> 2) + (co >> 2)] = (uint8_t)bits;
+        } else {
+          bf16x4 o;
+          o[0] = (bf16_t)f[0]; o[1] = (bf16_t)f[1]; o[2] = (bf16_t)f[2]; o[3] = (bf16_t)f[3];
+          *reinterpret_cast<bf16x4*>(op) = o;
+        }
+      }
+    }
+  }
+}
+
 // The plain epilogue of BOTH conv kernels (one copy: the register-staged and the LDS-DMA kernel differ only in how the
 // tiles reach LDS): channels-last stores of the accumulators -- 4 consecutive co per lane per fragment, 8 after the
 // permlane swap (`wide`) -- with the optional += of `accumulate`, the optional output ReLU bitmap (EPI == 2), and the
@@ -411,7 +538,8 @@ __device__ __forceinline__ void epilogue_plain(const ConvK& k, const f32x4 (&acc
   }
 }
 
-// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb), 2 output ReLU bitmap (out_relu_bits) -- own
+// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb), 2 output ReLU bitmap (out_relu_bits), 3 fused output
+// transform (sfk_conv_epilogue) -- own
 // instantiations: the extra epilogue state must not cost the plain kernel registers (the 256x128 tile sits at 128 VGPRs)
 template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, int EPI = 0>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kernel(const ConvK k) {
@@ -601,6 +729,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   if constexpr (EPI == 1 && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: its own instantiation
     __syncthreads();        // the partial sums go through LDS that aliases the ring
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    return;
+  }
+  if constexpr (EPI == 3) {
+    epilogue_fused<T, FM, FN, BM, BN, WM, WN>(k, acc, mt, nt, wm, wn, lane);
     return;
   }
   epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, true>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
@@ -817,6 +949,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
     epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
+  if constexpr (EPI == 3) {
+    epilogue_fused<T, FM, FN, BM, BN, WM, WN>(k, acc, mt, nt, wm, wn, lane);
+    return;
+  }
   epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, false>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
 }
 
@@ -859,6 +995,8 @@ inline bool relu_out_ok(const sfk_conv_desc* d) {
   return d->x.dtype == SFK_F32 ? true : bnb_ok(d);
 }
 
+inline bool ep_on(const sfk_conv_desc* d) { return d->ep.scale || d->ep.shift; }
+
 int validate(const sfk_conv_desc* d) {
   if (!d || !d->w) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
@@ -881,6 +1019,21 @@ int validate(const sfk_conv_desc* d) {
   if (d->out_relu_bits) {
     if (d->bnb.partials) return SFK_ERR_INVALID;
     if (!relu_out_ok(d)) return SFK_ERR_UNSUPPORTED;
+  }
+  if (ep_on(d)) {
+    const sfk_conv_epilogue& e = d->ep;
+    if (d->stats || d->bnb.partials || d->out_relu_bits) return SFK_ERR_INVALID;
+    if ((e.relu_bits && !e.relu) || (e.res_scale && !e.res.ptr) || (e.res_shift && !e.res.ptr)) return SFK_ERR_INVALID;
+    if (e.res.ptr && (!sfk_fmap_ok(&e.res) || e.res.n != d->y.n || e.res.t != d->y.t || e.res.h != d->y.h ||
+                      e.res.w != d->y.w || e.res.c != d->y.c || e.res.dtype != d->y.dtype))
+      return SFK_ERR_INVALID;
+    if (!lin_out_of(d)) return SFK_ERR_UNSUPPORTED;
+    if (d->x.dtype == SFK_BF16) {
+      // tiles with an even number of co fragments (cout > 16) store 16-byte channel groups; the one-fragment tile of the
+      // narrowest layers does scale / shift / += only
+      if (d->cout > 16 ? !bnb_ok(d) : (e.res.ptr || e.relu)) return SFK_ERR_UNSUPPORTED;
+    }
+    if (e.res.ptr && !sfk_fmap_vec_ok(&e.res)) return SFK_ERR_UNSUPPORTED;
   }
   if (d->bnb.partials) {
     const sfk_bn_bwd_fuse& b = d->bnb;
@@ -907,6 +1060,12 @@ int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
   if (k.bn_parts) {
     if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 1>), grid, dim3(512), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
+  if (k.ep_on) {
+    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 3>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
@@ -947,6 +1106,10 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
     k.bn_relu = d->bnb.relu;
     k.bn_mean = d->bnb.mean; k.bn_invstd = d->bnb.invstd; k.bn_scale = d->bnb.scale; k.bn_shift = d->bnb.shift;
   }
+  k.ep_on = ep_on(d) ? 1 : 0;
+  k.ep_scale = d->ep.scale; k.ep_shift = d->ep.shift; k.ep_rscale = d->ep.res_scale; k.ep_rshift = d->ep.res_shift;
+  k.ep_res = d->ep.res.ptr; k.ep_rld = d->ep.res.ld; k.ep_roff = d->ep.res.c_off;
+  k.ep_relu = d->ep.relu; k.ep_bits = d->ep.relu_bits;
   k.kshort = sfk_tune().igemm_short_k;
   k.lin_out = lin_out_of(d);
   const int wide_ok = sfk_tune().igemm_wide_store;
@@ -969,6 +1132,14 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       return SFK_OK;
     }
     return SFK_ERR_UNSUPPORTED;
+  }
+  if (k.ep_on) {             // fused output transform (look-ahead K loop for every K)
+    if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 3>), grid, block, 0, s, k);
+    else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 3>), grid, block, 0, s, k);
+    else if (ts.bn == 32) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 3>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 16, 4, 1, false, 3>), grid, block, 0, s, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
   }
   if (k.obits) {             // output ReLU bitmap: the look-ahead K loop also for short K (few launches, one instantiation less)
     if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 2>), grid, block, 0, s, k);
@@ -1008,6 +1179,10 @@ extern "C" int sfk_conv_relu_out_supported(const sfk_conv_desc* d) {
   c.out_relu_bits = nullptr;
   if (validate(&c) != SFK_OK) return 0;
   return relu_out_ok(d) ? 1 : 0;
+}
+
+extern "C" int sfk_conv_epilogue_supported(const sfk_conv_desc* d) {
+  return (d && ep_on(d) && validate(d) == SFK_OK) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_bnb_supported(const sfk_conv_desc* d) {

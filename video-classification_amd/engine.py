@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import arch
-from ._lib import BN_FOLD_ROWS, BnBwdFuse, ConvPass, FMap, StemSrc, WgradPass, stem_kp
+from ._lib import BN_FOLD_ROWS, BnBwdFuse, ConvEpilogue, ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from .plan import ConvGeom, dgrad_passes, fwd_pass, round_up, wgrad_taps
 
 Run = Callable[[int], None]
@@ -150,6 +150,11 @@ class Engine:
         # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
         # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
         self.deterministic_wgrad = os.environ.get("SFK_WGWS", "0") == "1"
+        # The bottleneck tail conv_c -> norm_c -> (+ shortcut) -> ReLU without the conv output in HBM (include/sfk.h,
+        # sfk_bn_tail_*): statistics from the Gram matrix of conv_c's input, BatchNorm + shortcut + ReLU in the conv
+        # epilogue, and a backward that needs neither y_c nor dy_c.  Per block with conv_c inputs of >= tail_min_c channels.
+        self.fuse_tail = os.environ.get("SFK_TAIL", "1") != "0" and hasattr(self.be, "bn_tail_fwd")
+        self.tail_min_c = int(os.environ.get("SFK_TAIL_MINC", "8"))
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -577,6 +582,128 @@ class Engine:
         self._wgrad(pl, rec, dy)
         self._dgrad(pl, rec, dy, d_xf, accumulate=True)
 
+    # ---- bottleneck tail: conv_c -> norm_c -> + shortcut -> ReLU with no conv output in HBM (sfk.h: sfk_bn_tail_*)
+    TAP0 = [(0, 0, 0, 0)]
+
+    def _tail_ok(self, Lc: _Layer) -> bool:
+        g = Lc.cb.geom
+        return (self.fuse_tail and self.relu_bits and g.k == (1, 1, 1) and g.s == (1, 1, 1)
+                and self.tail_min_c <= g.cin <= 512 and g.cout > 16 and g.cout % self.kvec == 0)
+
+    def _ws_wgrad(self, oplist: "OpList", wp: WgradPass, key, **meta):
+        """a filter-gradient call that sums its pixel splits through the lane's scratch (deterministic); the scratch is
+        sized and bound at the end of plan construction (_build_plan)"""
+        need = self.be.conv_wgrad_workspace_bytes(wp)
+        if need > 0:
+            self._wg_ws_need[key] = max(self._wg_ws_need.get(key, 0), need)
+            self._wg_pending.append((oplist, len(oplist), wp, key))
+        oplist.append(self.be.conv_wgrad(wp), **meta)
+
+    def _tail_fwd(self, pl, blk, Lc: _Layer, yb: FMap, sb, hb, res: FMap, rs, rh, out: FMap, tag: str, train: bool):
+        """norm_b apply -> [Gram matrix -> statistics] -> conv_c with BatchNorm + shortcut + ReLU in its epilogue"""
+        n, c4, C = yb.n, Lc.eg.cin, Lc.eg.cout
+        V = self.kvec
+        gld = c4 + V
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        # conv_c's input lives widened by one channel group whose first channel is the constant 1 (set here, once: kernels
+        # only ever write the c4 data channels); the tag carries the geometry so no other plan's layout shares the buffer
+        full = self._fmap(f"a.{tag}.b.w{n}x{yb.t}x{yb.h}x{yb.w}", n, yb.t, yb.h, yb.w, gld)
+        full.view5()[..., c4:] = 0
+        full.view5()[..., c4] = 1
+        ab = full.channels(0, c4)
+        self._apply(pl, yb, sb, hb, None, None, None, True, ab)
+        scale = self._buf(f"scale.{tag}.c", C, torch.float32)
+        shift = self._buf(f"shift.{tag}.c", C, torch.float32)
+        gamma, beta = self._pslice(Lc.g_off, C), self._pslice(Lc.b_off, C)
+        w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
+        tail = None
+        if train:
+            gram = self._tail_zero("f", gld * gld)
+            lane = pl.fwd.cur_lane
+            self._ws_wgrad(pl.fwd, WgradPass(full, full, (1, 1, 1), self.TAP0, gram, 1, gld, gld), f"f{lane}",
+                           kind="conv_wgrad", layer=Lc.cb.conv_key + ":gram", cout=gld,
+                           flops=2.0 * full.pixels * gld * gld, bytes=float(esz * full.pixels * gld + 4 * gld * gld))
+            mean = self._buf(f"mean.{tag}.c", C, torch.float32)
+            invstd = self._buf(f"invstd.{tag}.c", C, torch.float32)
+            t = self._buf(f"tailT.{tag}", C * c4, torch.float32)
+            pl.fwd.append(self.be.bn_tail_fwd(gram, c4, gld, w, C, gamma, beta, self.spec.bn_eps, self.spec.bn_momentum,
+                                              Lc.rm, Lc.rv, Lc.nbt, mean, invstd, scale, shift, t))
+            tail = dict(full=full, ab=ab, gram=gram, t=t, mean=mean, invstd=invstd, gld=gld)
+        else:
+            pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, Lc.rm, Lc.rv, self.spec.bn_eps, C, scale, shift))
+        bits = self._buf(f"relubits.{tag}", out.pixels * (C // V), torch.uint8) if train else None
+        cp = ConvPass(ab, out, (ab.t, ab.h, ab.w), (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, w, 1, c4, C,
+                      ep=ConvEpilogue(scale=scale, shift=shift, res=res, res_scale=rs, res_shift=rh, relu=True, relu_bits=bits))
+        pl.fwd.append(self.be.conv_igemm(cp), kind="conv_fwd", layer=Lc.cb.conv_key, cout=C,
+                      flops=2.0 * ab.pixels * C * c4,
+                      bytes=float(esz * (ab.pixels * c4 + 2 * ab.pixels * C + Lc.w_numel) + (ab.pixels * C // V if train else 0)))
+        return tail, bits
+
+    def _tail_zero_layout(self, train: bool):
+        """fp32 scratch that must be ZERO when its producer (a += filter-gradient call) runs -- the Gram matrices of the
+        forward, R and W^T B W of the backward -- is carved out of one flat buffer per schedule, cleared by ONE fill at the
+        schedule's start.  Sizes depend on the wiring only, so the buffers exist before the first op is built."""
+        V = self.kvec
+        nf = nb = 0
+        for stage in self.wiring.stages:
+            for blocks in stage:
+                for blk in blocks:
+                    Lc = self._layers[blk.conv_c.conv_key]
+                    if self._tail_ok(Lc):
+                        c4, C = Lc.eg.cin, Lc.eg.cout
+                        nf += round_up((c4 + V) ** 2, 64)
+                        nb += round_up(C * (c4 + V), 64) + round_up(c4 * c4, 64)
+        self._tailz = {"f": self._buf("tailz.f", nf, torch.float32)[:nf] if (train and nf) else None,
+                       "b": self._buf("tailz.b", nb, torch.float32)[:nb] if (train and nb) else None}
+        self._tailz_off = {"f": 0, "b": 0}
+
+    def _tail_zero(self, key: str, numel: int) -> torch.Tensor:
+        off = self._tailz_off[key]
+        self._tailz_off[key] = off + round_up(numel, 64)
+        return self._tailz[key][off:off + numel]
+
+    def _tail_bwd(self, pl, Lc: _Layer, tail: dict, d_out: FMap, dab: FMap, tag: str):
+        """dz (in d_out) -> dgamma, dbeta, dW of conv_c / norm_c and d(a_b) in dab, without y_c or dy_c:
+        R = dz^T [a_b | 1], the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
+        c4, C, gld = Lc.eg.cin, Lc.eg.cout, tail["gld"]
+        full, ab = tail["full"], tail["ab"]
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
+        rx = self._tail_zero("b", C * gld)
+        wp = WgradPass(full, d_out, (1, 1, 1), self.TAP0, rx, 1, gld, C)
+        meta = dict(kind="conv_wgrad", layer=Lc.cb.conv_key, cout=C, flops=2.0 * d_out.pixels * C * gld,
+                    bytes=float(esz * (full.pixels * gld + d_out.pixels * C) + 4 * C * gld))
+        if self.deterministic_wgrad:
+            self._ws_wgrad(pl.bwd, wp, f"b{pl.bwd.cur_lane}", **meta)
+        else:
+            pl.bwd.append(self.be.conv_wgrad(wp), **meta)
+        wd = self._buf(f"tailWd.{tag}", C * c4)
+        ws = self._buf(f"tailWs.{tag}", C * c4)
+        bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
+        coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
+        pl.bwd.append(self.be.bn_tail_bwd(rx, tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
+                                          tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
+                                          self._gslice(Lc.w_off, Lc.w_numel), wd, ws, bias, coef))
+        pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
+        pl.grad_marks.append((len(pl.bwd), (Lc.w_off, round_up(Lc.w_numel, self.vec))))
+        # m = W^T diag(B) W: one more filter-gradient call, its "pixels" are conv_c's output channels
+        m32 = self._tail_zero("b", c4 * c4)
+        wmap, wsmap = FMap(w, 1, 1, 1, C, c4), FMap(ws, 1, 1, 1, C, c4)
+        pl.bwd.append(self.be.conv_wgrad(WgradPass(wmap, wsmap, (1, 1, 1), self.TAP0, m32, 1, c4, c4)))
+        if self.dtype == torch.float32:
+            m = m32
+        else:
+            m = self._buf(f"tailM.{tag}", c4 * c4)
+            pl.bwd.append(self.be.cast(m32, m, c4 * c4))
+        rows = (d_out.t, d_out.h, d_out.w)
+        pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, wd, 1, C, c4)),
+                      kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
+                      bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
+        pl.bwd.append(self.be.conv_igemm(ConvPass(ab, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, m, 1, c4, c4,
+                                                  accumulate=True, ep=ConvEpilogue(shift=bias))),
+                      kind="conv_dgrad", layer=Lc.cb.conv_key + ":m", cout=c4, flops=2.0 * d_out.pixels * c4 * c4,
+                      bytes=float(esz * 3 * d_out.pixels * c4))
+
     # ---- bottleneck residual block
     def _block_fwd(self, pl, blk: arch.Block, x: FMap, out: FMap, tag: str, train: bool):
         n = x.n
@@ -590,6 +717,11 @@ class Engine:
         aa = self._fmap(f"a.{tag}.a", n, ya.t, ya.h, ya.w, La.c)
         self._apply(pl, ya, sa, ha, None, None, None, True, aa)
         yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n)
+        if self._tail_ok(Lc):
+            assert (yb.t, yb.h, yb.w, Lc.c) == (out.t, out.h, out.w, out.c)
+            res, rs, rh = (y1, s1, h1) if blk.branch1 is not None else (x, None, None)
+            tail, bits = self._tail_fwd(pl, blk, Lc, yb, sb, hb, res, rs, rh, out, tag, train)
+            return (blk, tag, x, out, rec1, reca, recb, tail, bits)
         ab = self._fmap(f"a.{tag}.b", n, yb.t, yb.h, yb.w, Lb.c)
         self._apply(pl, yb, sb, hb, None, None, None, True, ab)
         yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n)
@@ -611,15 +743,24 @@ class Engine:
         is then what to hand to prev's _block_bwd."""
         blk, tag, x, out, rec1, reca, recb, recc, bits = brec
         n = x.n
-        # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
-        dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
-        if reduced_c == "masked":     # the pass that finished d_out applied this block's ReLU bitmap: d_out holds dz
-            self._bn_bwd(pl, recc, d_out, f"{tag}.c", False, None, False, dyc)
-        else:
-            self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
-        self._wgrad(pl, recc, dyc)
         dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
-        red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
+        if isinstance(recc, dict):    # fused tail: no y_c, no dy_c (sfk_bn_tail_bwd)
+            assert reduced_c is None or reduced_c == "masked"
+            if reduced_c != "masked":                 # the block output's ReLU mask, in place: d_out becomes dz
+                esz = 2 if self.dtype == torch.bfloat16 else 4
+                pl.bwd.append(self.be.relu_bits_mask(d_out, bits, d_out), kind="bn_bwd_reduce", layer=f"{tag}.mask",
+                              bytes=float(d_out.pixels * d_out.c * (2 * esz) + d_out.pixels * d_out.c // self.kvec))
+            self._tail_bwd(pl, self._layers[blk.conv_c.conv_key], recc, d_out, dab, tag)
+            red_b = None
+        else:
+            # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
+            dyc = self._fmap(f"dy.{tag}.c", n, recc.y.t, recc.y.h, recc.y.w, recc.y.c)
+            if reduced_c == "masked":     # the pass that finished d_out applied this block's ReLU bitmap: d_out holds dz
+                self._bn_bwd(pl, recc, d_out, f"{tag}.c", False, None, False, dyc)
+            else:
+                self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
+            self._wgrad(pl, recc, dyc)
+            red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
         self._bn_bwd(pl, recb, dab, f"{tag}.b", True, None, False, dab, reduced=red_b)
         self._wgrad(pl, recb, dab)
         daa = self._fmap(f"da.{tag}.a", n, reca.y.t, reca.y.h, reca.y.w, reca.y.c)
@@ -629,7 +770,7 @@ class Engine:
         if rec1 is None:
             # identity shortcut: dX = dz + dgrad_a; dX is the gradient of the previous block's output
             fuse = None
-            if prev is not None:
+            if prev is not None and not isinstance(prev[7], dict):
                 p_tag, p_out, p_recc = prev[1], prev[3], prev[7]
                 fuse = (p_recc, p_out, True, f"{p_tag}.c")
             p_bits = prev[8] if (prev is not None and self.relu_out_mask) else None
@@ -655,6 +796,7 @@ class Engine:
         be, spec, W = self.be, self.spec, self.wiring
         pl = Plan()
         self._wg_ws_need, self._wg_pending = {}, []
+        self._tail_zero_layout(train)
         NP = spec.pathways                              # 2: SlowFast; 1: the single-pathway `res3d` network (slow_r50)
         n = x_slow.shape[0]
         # ---- refresh the compute-precision filter copies from the fp32 master arena
@@ -664,6 +806,8 @@ class Engine:
                                             self.St if train else None,
                                             [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad)
                                              for L in self.layers]))
+        if self._tailz["f"] is not None:
+            pl.fwd.append(be.fill_zero(self._tailz["f"]))
         # ---- geometry after the stems
         def stem_out(x5, p, t_idx):
             g = W.stems[p].geom
@@ -753,11 +897,14 @@ class Engine:
         fcw, fcb = self._pslice(self.fc_w_off, F * K), self._pslice(self.fc_b_off, K)
         pl.fwd.append(be.fc_fwd(feat, fcw, fcb, pl.logits, n, F, K))
         if not train:
+            self._bind_wgrad_scratch()
             return pl
 
         # ================================================================= backward schedule
         pl.dlogits = self._buf("dlogits", n * K, torch.float32)[: n * K].view(n, K)
         dfeat = self._buf("dfeat", n * F, torch.float32)
+        if self._tailz["b"] is not None:
+            pl.bwd.append(be.fill_zero(self._tailz["b"]))
         pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, self._gslice(self.fc_w_off, F * K),
                                 self._gslice(self.fc_b_off, K), n, F, K))
         pl.grad_marks.append((len(pl.bwd), (self.fc_w_off, self.layers[0].g_off - self.fc_w_off)))
@@ -792,12 +939,15 @@ class Engine:
             if NP == 2:
                 B_.sync(0, 3)
         B_.cur_lane = 0
-        # bind the filter-gradient ops to their lane's scratch now that its size is known
+        self._bind_wgrad_scratch()
+        return pl
+
+    def _bind_wgrad_scratch(self):
+        """bind the filter-gradient ops to their lane's scratch now that its size is known"""
         for oplist, slot, wp, lane in self._wg_pending:
             wp.workspace = self._buf(f"wgws.{lane}", (self._wg_ws_need[lane] + 3) // 4, torch.float32)
             oplist[slot] = self.be.conv_wgrad(wp)
         self._wg_pending = []
-        return pl
 
     # ------------------------------------------------------------------ execution
     def _plan_for(self, x_slow, x_fast, slow_t_index, train: bool) -> Plan:
