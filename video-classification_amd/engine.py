@@ -155,6 +155,9 @@ class Engine:
         # epilogue, and a backward that needs neither y_c nor dy_c.  Per block with conv_c inputs of >= tail_min_c channels.
         self.fuse_tail = os.environ.get("SFK_TAIL", "1") != "0" and hasattr(self.be, "bn_tail_fwd")
         self.tail_min_c = int(os.environ.get("SFK_TAIL_MINC", "8"))
+        # upper bound: the tail's fixed cost is O(cout * c^2) (T = W G, W^T B W) whatever the map size, what it saves is
+        # O(pixels * cout) -- it pays on the large maps of the early stages (c <= 128), not on res4 / res5 (c = 256 / 512)
+        self.tail_max_c = int(os.environ.get("SFK_TAIL_MAXC", "128"))
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -588,7 +591,7 @@ class Engine:
     def _tail_ok(self, Lc: _Layer) -> bool:
         g = Lc.cb.geom
         return (self.fuse_tail and self.relu_bits and g.k == (1, 1, 1) and g.s == (1, 1, 1)
-                and self.tail_min_c <= g.cin <= 512 and g.cout > 16 and g.cout % self.kvec == 0)
+                and self.tail_min_c <= g.cin <= min(512, self.tail_max_c) and g.cout > 16 and g.cout % self.kvec == 0)
 
     def _ws_wgrad(self, oplist: "OpList", wp: WgradPass, key, **meta):
         """a filter-gradient call that sums its pixel splits through the lane's scratch (deterministic); the scratch is
