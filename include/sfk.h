@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 5
+#define SFK_ABI_VERSION 6
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -163,6 +163,9 @@ typedef struct {
    * it avoids re-adding every tile through fp32 atomics (~1.3 TB/s chip-wide).  NULL / too small: atomics. */
   float* workspace;
   int64_t workspace_bytes;
+  /* optional [cout] fp32: sum_dy[co] += sum over the rows of dY[.., co] (one more MFMA per fragment against a ones operand;
+   * added with float atomics, also when `workspace` is used).  The BatchNorm backward of a fused block tail needs it. */
+  float* sum_dy;
 } sfk_wgrad_desc;
 
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
@@ -266,7 +269,7 @@ int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_f
  * The caller keeps `a` with ONE extra channel group whose first channel is the constant 1 (pixel stride ld = c + V,
  * V = 16 / sizeof(dtype)), so the ordinary filter-gradient kernel delivers everything in two calls:
  *     gram = sfk_conv_wgrad(x = a[0 : c+V), dy = a[0 : c+V))  -> [c+V][c+V]: G, row c = g, element (c, c) = n
- *     rx   = sfk_conv_wgrad(x = a[0 : c+V), dy = dz)          -> [cout][c+V]: R, column c = s
+ *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz, sum_dy = sdz) -> [cout][c]: R, and sdz[co] = s
  * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift exactly as sfk_bn_finalize, from `gram`; also
  *   leaves t = W G ([cout][c] fp32) for the backward.  w = the conv's filter [cout][c] in compute precision (w_dtype).
  * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the two data-gradient passes
@@ -279,10 +282,10 @@ int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, in
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
                     float* shift, float* t, sfk_stream_t stream);
-int sfk_bn_tail_bwd(const float* rx, const float* gram, const float* t, int32_t c, int32_t gld, const void* w,
-                    int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
-                    float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
-                    sfk_stream_t stream); /* coef: [cout][4] fp32 scratch */
+int sfk_bn_tail_bwd(const float* r, const float* sdz, const float* gram, const float* t, int32_t c, int32_t gld,
+                    const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean,
+                    const float* invstd, float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias,
+                    float* coef, sfk_stream_t stream); /* r [cout][c], sdz [cout]; coef: [cout][4] fp32 scratch */
 
 /* ---------------------------------------------------------------------------------------------------------
  * MaxPool3d (1,k,k)/(1,s,s)/(0,p,p) of the stems (my_slowfast.py:66-68).  `argmax` (uint8 per output

@@ -164,10 +164,10 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
-    def bn_tail_bwd(self, rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
+    def bn_tail_bwd(self, r, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
         def run(stream):
-            Rx = rx[: cout * gld].view(cout, gld).double()
-            R, s_ = Rx[:, :c], Rx[:, c]
+            R = r[: cout * c].view(cout, c).double()
+            s_ = sdz[:cout].double()
             Gx = gram[: gld * gld].view(gld, gld).double()
             g, n = Gx[c, :c], float(Gx[c, c])
             W = w[: cout * c].view(cout, c).double()
@@ -194,6 +194,8 @@ class EmuBackend:
             dw = p.dw[: p.cout * p.wtaps * p.cin].view(p.cout, p.wtaps, p.cin)
             for tap in p.taps:
                 dw[:, tap[3], :] += torch.einsum("nthwo,nthwc->oc", dY, _gather(X, rows, p.gs, tap))
+            if getattr(p, "sum_dy", None) is not None:
+                p.sum_dy[: p.cout].add_(dY.reshape(-1, p.cout).sum(0))
         return run
 
     @staticmethod

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 5        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 6        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -127,6 +127,7 @@ class WgradPass:
     cin: int
     cout: int
     workspace: Optional[torch.Tensor] = None   # fp32 scratch for the partial-tile path (sfk_conv_wgrad_workspace_bytes)
+    sum_dy: Optional[torch.Tensor] = None      # fp32 [cout]: += column sums of dy (sfk_wgrad_desc.sum_dy)
 
 
 @dataclass
@@ -176,7 +177,7 @@ class _ConvDesc(C.Structure):
 class _WgradDesc(C.Structure):
     _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("sum_dy", C.c_void_p)]
 
 
 class _StemSrc(C.Structure):
@@ -214,7 +215,7 @@ SIGNATURES = {
     "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
     "sfk_relu_bits_mask": [_P_FMAP, _PV, _P_FMAP, _PV],
     "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
-    "sfk_bn_tail_bwd": [_PF, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
+    "sfk_bn_tail_bwd": [_PF, _PF, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
@@ -400,6 +401,9 @@ class HipBackend:
         d.gs = (C.c_int32 * 3)(*p.gs)
         d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)
         d.dw, d.wtaps, d.cin, d.cout = p.dw.data_ptr(), p.wtaps, p.cin, p.cout
+        if p.sum_dy is not None:
+            assert p.sum_dy.dtype == torch.float32 and p.sum_dy.numel() >= p.cout
+            d.sum_dy = p.sum_dy.data_ptr()
         return d
 
     def conv_wgrad_workspace_bytes(self, p: WgradPass) -> int:
@@ -549,11 +553,11 @@ class HipBackend:
                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
                            _ptr(scale), _ptr(shift), _ptr(t), keep=ts)
 
-    def bn_tail_bwd(self, rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
-        ts = (rx, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
-        return self._plain("sfk_bn_tail_bwd", _ptr(rx), _ptr(gram), _ptr(t), c, gld, _ptr(w), _DT[w.dtype], cout, _ptr(gamma),
-                           _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(wd), _ptr(ws), _ptr(bias),
-                           _ptr(coef), keep=ts)
+    def bn_tail_bwd(self, r, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
+        ts = (r, sdz, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
+        return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(sdz), _ptr(gram), _ptr(t), c, gld, _ptr(w), _DT[w.dtype], cout,
+                           _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(wd), _ptr(ws),
+                           _ptr(bias), _ptr(coef), keep=ts)
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

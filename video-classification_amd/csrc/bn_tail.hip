@@ -3,7 +3,7 @@
 //
 // What the big kernels deliver (ordinary sfk_conv_wgrad calls over `a` widened by a constant-1 channel):
 //     gram [c+V][c+V] fp32 : G = a^T a, row c = column sums g, element (c,c) = pixel count n
-//     rx   [cout][c+V] fp32: R = dz^T a, column c = s = sum dz
+//     r    [cout][c] fp32  : R = dz^T a, and sdz [cout] = s = sum dz (sfk_wgrad_desc.sum_dy of the same call)
 // What this file computes from them -- everything is O(cout * c^2) or less, i.e. independent of the pixel count:
 //     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift
 //     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the two data-gradient passes
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
                                                           int64_t* nbt, float* mean, float* invstd, float* scale,
                                                           float* shift, float* __restrict__ t) {
   __shared__ float wl[TF_CO][TF_MAXC];
-  __shared__ double red[256][2];
+  __shared__ double red[4 * TF_CO][2];
   const int co0 = blockIdx.x * TF_CO, tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0 && nbt) nbt[0] += 1;
   for (int i = tid; i < TF_CO * c; i += 256) {
@@ -57,63 +57,72 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
     }
   }
   const double n = (double)gram[(int64_t)c * gld + c];
-  for (int o = 0; o < TF_CO; ++o) {            // (uniform trip count: the barriers inside are reached by every thread)
-    double p1 = 0.0, p2 = 0.0;
+  // per channel: p1 = W[co] . g, p2 = T[co] . W[co]; wave butterflies in double, then 4 waves through LDS (fixed order)
+  double p1[TF_CO], p2[TF_CO];
+#pragma unroll
+  for (int o = 0; o < TF_CO; ++o) {
+    p1[o] = 0.0;
+    p2[o] = 0.0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int ci = tid + 256 * r;
       if (ci < c) {
         if (co0 + o < cout) t[(int64_t)(co0 + o) * c + ci] = acc[o][r];
-        p1 += (double)wl[o][ci] * (double)gram[(int64_t)c * gld + ci];
-        p2 += (double)acc[o][r] * (double)wl[o][ci];
+        p1[o] += (double)wl[o][ci] * (double)gram[(int64_t)c * gld + ci];
+        p2[o] += (double)acc[o][r] * (double)wl[o][ci];
       }
     }
-    red[tid][0] = p1;
-    red[tid][1] = p2;
-    __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) {   // fixed tree: deterministic
-      if (tid < sft) {
-        red[tid][0] += red[tid + sft][0];
-        red[tid][1] += red[tid + sft][1];
-      }
-      __syncthreads();
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      p1[o] += __shfl_xor(p1[o], sft);
+      p2[o] += __shfl_xor(p2[o], sft);
     }
-    if (tid == 0 && co0 + o < cout) {
-      const int ch = co0 + o;
-      const double mu = red[0][0] / n;
-      double var = red[0][1] / n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      const float is = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = gamma[ch] * is;
-      mean[ch] = (float)mu;
-      invstd[ch] = is;
-      scale[ch] = sc;
-      shift[ch] = beta[ch] - (float)mu * sc;
-      if (running_mean) {
-        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
-        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
-      }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int o = 0; o < TF_CO; ++o) {
+      red[(tid >> 6) * TF_CO + o][0] = p1[o];
+      red[(tid >> 6) * TF_CO + o][1] = p2[o];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < TF_CO && co0 + tid < cout) {
+    const int ch = co0 + tid;
+    const double s1 = red[tid][0] + red[TF_CO + tid][0] + red[2 * TF_CO + tid][0] + red[3 * TF_CO + tid][0];
+    const double s2 = red[tid][1] + red[TF_CO + tid][1] + red[2 * TF_CO + tid][1] + red[3 * TF_CO + tid][1];
+    const double mu = s1 / n;
+    double var = s2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * is;
+    mean[ch] = (float)mu;
+    invstd[ch] = is;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (float)mu * sc;
+    if (running_mean) {
+      const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+    }
   }
 }
 
 // one wave per output channel: sum dz*y = W[co] . R[co]; coefficients of dy = A dz + B y + C; dgamma, dbeta
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ gram,
-                                                           int c, int gld, const void* w, int cout, const float* gamma,
+__global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ sdz,
+                                                           const float* __restrict__ gram, int c, int gld, const void* w,
+                                                           int cout, const float* gamma,
                                                            const float* mean, const float* invstd, float* dgamma,
                                                            float* dbeta, float* coef) {
   const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (co >= cout) return;
   double sdy = 0.0;
-  for (int ci = lane; ci < c; ci += 64) sdy += (double)wload<D>(w, (int64_t)co * c + ci) * (double)rx[(int64_t)co * gld + ci];
+  for (int ci = lane; ci < c; ci += 64) sdy += (double)wload<D>(w, (int64_t)co * c + ci) * (double)rx[(int64_t)co * c + ci];
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) sdy += __shfl_xor(sdy, sft);
   if (lane != 0) return;
   const double n = (double)gram[(int64_t)c * gld + c];
-  const double s = (double)rx[(int64_t)co * gld + c];
+  const double s = (double)sdz[co];
   const double is = (double)invstd[co], mu = (double)mean[co];
   const double sxh = is * (sdy - mu * s);                 // sum dz * x_hat
   dgamma[co] += (float)sxh;
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restr
       const float A = coef[co * 4], B = coef[co * 4 + 1], Cc = coef[co * 4 + 2];
       const int64_t idx = (int64_t)co * c + ci;
       const float wv = wload<D>(w, idx);
-      dw[idx] += A * rx[(int64_t)co * gld + ci] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
+      dw[idx] += A * rx[idx] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
       ws[idx] = (D)(B * wv);
       aw = A * wv;
     }
@@ -156,18 +165,26 @@ __global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restr
   }
 }
 
-// bias[ci] = sum_co C[co] W[co][ci]: 64 columns x 4 row partitions per block
+// bias[ci] = sum_co C[co] W[co][ci]: 16 columns x 16 row partitions per block, fixed summation order
 template <typename D>
 __global__ __launch_bounds__(256) void bn_tail_bias_kernel(const void* w, int c, int cout, const float* __restrict__ coef,
                                                            float* bias) {
-  __shared__ double red[4][64];
-  const int ci = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ double red[16][17];
+  const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int ci = blockIdx.x * 16 + col;
   double s = 0.0;
-  if (ci < c)
-    for (int co = part; co < cout; co += 4) s += (double)coef[co * 4 + 2] * (double)wload<D>(w, (int64_t)co * c + ci);
-  red[part][threadIdx.x & 63] = s;
+  if (ci < c) {
+#pragma unroll 4
+    for (int co = part; co < cout; co += 16) s += (double)coef[co * 4 + 2] * (double)wload<D>(w, (int64_t)co * c + ci);
+  }
+  red[part][col] = s;
   __syncthreads();
-  if (part == 0 && ci < c) bias[ci] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (part == 0 && ci < c) {
+    double a = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) a += red[p][col];
+    bias[ci] = (float)a;
+  }
 }
 
 // dz = da * mask(bitmap): 16 bytes per thread, one bitmap byte each
@@ -214,29 +231,29 @@ extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const 
 }
 
 template <typename D>
-static int tail_bwd_launch(const float* rx, const float* gram, const float* t, int c, int gld, const void* w, int cout,
+static int tail_bwd_launch(const float* rx, const float* sdz, const float* gram, const float* t, int c, int gld, const void* w, int cout,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                            float* dw, void* wd, void* ws, float* bias, float* coef, hipStream_t s) {
-  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, gram, c, gld, w, cout, gamma, mean,
+  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, sdz, gram, c, gld, w, cout, gamma, mean,
                      invstd, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_tail_apply_kernel<D>, dim3((c + 31) / 32, (cout + 31) / 32), dim3(256), 0, s, rx, gram, t, c, gld,
                      w, cout, coef, dw, static_cast<D*>(wd), static_cast<D*>(ws));
-  hipLaunchKernelGGL(bn_tail_bias_kernel<D>, dim3((c + 63) / 64), dim3(256), 0, s, w, c, cout, coef, bias);
+  hipLaunchKernelGGL(bn_tail_bias_kernel<D>, dim3((c + 15) / 16), dim3(256), 0, s, w, c, cout, coef, bias);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
 
-extern "C" int sfk_bn_tail_bwd(const float* rx, const float* gram, const float* t, int32_t c, int32_t gld, const void* w,
-                               int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
+extern "C" int sfk_bn_tail_bwd(const float* rx, const float* sdz, const float* gram, const float* t, int32_t c, int32_t gld,
+                               const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
                                float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
                                sfk_stream_t stream) {
-  if (!rx || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
+  if (!rx || !sdz || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
     return SFK_ERR_INVALID;
   if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return w_dtype == SFK_BF16
-             ? tail_bwd_launch<bf16_t>(rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
-             : tail_bwd_launch<float>(rx, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
+             ? tail_bwd_launch<bf16_t>(rx, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
+             : tail_bwd_launch<float>(rx, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
 }
 
 extern "C" int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_fmap* dz, sfk_stream_t stream) {

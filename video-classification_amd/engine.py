@@ -655,7 +655,7 @@ class Engine:
                     if self._tail_ok(Lc):
                         c4, C = Lc.eg.cin, Lc.eg.cout
                         nf += round_up((c4 + V) ** 2, 64)
-                        nb += round_up(C * (c4 + V), 64) + round_up(c4 * c4, 64)
+                        nb += round_up(C * c4, 64) + round_up(C, 64) + round_up(c4 * c4, 64)
         self._tailz = {"f": self._buf("tailz.f", nf, torch.float32)[:nf] if (train and nf) else None,
                        "b": self._buf("tailz.b", nb, torch.float32)[:nb] if (train and nb) else None}
         self._tailz_off = {"f": 0, "b": 0}
@@ -667,15 +667,15 @@ class Engine:
 
     def _tail_bwd(self, pl, Lc: _Layer, tail: dict, d_out: FMap, dab: FMap, tag: str):
         """dz (in d_out) -> dgamma, dbeta, dW of conv_c / norm_c and d(a_b) in dab, without y_c or dy_c:
-        R = dz^T [a_b | 1], the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
+        R = dz^T a_b (and s = sum dz from the same call), the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
         c4, C, gld = Lc.eg.cin, Lc.eg.cout, tail["gld"]
         full, ab = tail["full"], tail["ab"]
         esz = 2 if self.dtype == torch.bfloat16 else 4
         w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
-        rx = self._tail_zero("b", C * gld)
-        wp = WgradPass(full, d_out, (1, 1, 1), self.TAP0, rx, 1, gld, C)
-        meta = dict(kind="conv_wgrad", layer=Lc.cb.conv_key, cout=C, flops=2.0 * d_out.pixels * C * gld,
-                    bytes=float(esz * (full.pixels * gld + d_out.pixels * C) + 4 * C * gld))
+        r, sdz = self._tail_zero("b", C * c4), self._tail_zero("b", C)
+        wp = WgradPass(ab, d_out, (1, 1, 1), self.TAP0, r, 1, c4, C, sum_dy=sdz)
+        meta = dict(kind="conv_wgrad", layer=Lc.cb.conv_key, cout=C, flops=2.0 * d_out.pixels * C * c4,
+                    bytes=float(esz * (ab.pixels * c4 + d_out.pixels * C) + 4 * C * c4))
         if self.deterministic_wgrad:
             self._ws_wgrad(pl.bwd, wp, f"b{pl.bwd.cur_lane}", **meta)
         else:
@@ -684,7 +684,7 @@ class Engine:
         ws = self._buf(f"tailWs.{tag}", C * c4)
         bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
         coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
-        pl.bwd.append(self.be.bn_tail_bwd(rx, tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
+        pl.bwd.append(self.be.bn_tail_bwd(r, sdz, tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
                                           tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
                                           self._gslice(Lc.w_off, Lc.w_numel), wd, ws, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
