@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 6
+#define SFK_ABI_VERSION 7
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -91,6 +91,8 @@ typedef struct {
  *     partials[tile][cout][2] = (sum dz, sum dz * x_hat),  x_hat = (y_bn - mean) * invstd,  tile < sfk_conv_igemm_mtiles(d)
  * for sfk_bn_bwd_finalize -- sfk_bn_bwd_reduce's result without its three tensor reads and one write.
  * y_bn / mask_src share Y's pixel grid and channel count (own ld / c_off).  partials == NULL: off.
+ * y_bn.ptr == NULL together with sfk_conv_desc.out_relu_bits: the mask is that bitmap and only  sum dz  is left
+ * (partials[tile][co] = (sum dz, 0)) -- what the fused block tail (sfk_bn_tail_bwd) needs of the BatchNorm reduce.
  * Supported when sfk_conv_bnb_supported(d) != 0 (bf16, 8-channel groups 16-byte addressable, cout > 16). */
 typedef struct {
   sfk_fmap y_bn;
@@ -163,9 +165,6 @@ typedef struct {
    * it avoids re-adding every tile through fp32 atomics (~1.3 TB/s chip-wide).  NULL / too small: atomics. */
   float* workspace;
   int64_t workspace_bytes;
-  /* optional [cout] fp32: sum_dy[co] += sum over the rows of dY[.., co] (one more MFMA per fragment against a ones operand;
-   * added with float atomics, also when `workspace` is used).  The BatchNorm backward of a fused block tail needs it. */
-  float* sum_dy;
 } sfk_wgrad_desc;
 
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
@@ -242,6 +241,7 @@ int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
  *   finalize: dgamma (+)= sum dz*xhat, dbeta (+)= sum dz; coef[c][3] = (gamma*invstd, sum dz/count, sum dz*xhat/count)
  *   apply: dy = coef0 * (dz - coef1 - xhat*coef2)
  */
+/* y == NULL (needs relu_bits): only the mask is applied and partials = (sum dz, 0) -- the fused block tail's variant */
 int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                       const float* invstd, const float* scale, const float* shift, int32_t relu,
                       const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
@@ -252,9 +252,6 @@ int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_
 int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                      const float* invstd, const float* scale, const float* shift, int32_t relu,
                      const float* coef, const sfk_fmap* dy, sfk_stream_t stream);
-
-/* dz = da * mask, mask = the ReLU bitmap sfk_bn_apply / sfk_conv_epilogue left (in place when dz aliases da). */
-int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_fmap* dz, sfk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * The block tail  a -> conv_c (1x1x1, bias=False) -> norm_c (BatchNorm3d) [-> + shortcut -> ReLU]  WITHOUT the conv output
@@ -269,7 +266,8 @@ int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_f
  * The caller keeps `a` with ONE extra channel group whose first channel is the constant 1 (pixel stride ld = c + V,
  * V = 16 / sizeof(dtype)), so the ordinary filter-gradient kernel delivers everything in two calls:
  *     gram = sfk_conv_wgrad(x = a[0 : c+V), dy = a[0 : c+V))  -> [c+V][c+V]: G, row c = g, element (c, c) = n
- *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz, sum_dy = sdz) -> [cout][c]: R, and sdz[co] = s
+ *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz)            -> [cout][c]: R;  s = sum dz comes as partial rows from the
+ *            kernel that wrote dz (its ReLU-mask pass)
  * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift exactly as sfk_bn_finalize, from `gram`; also
  *   leaves t = W G ([cout][c] fp32) for the backward.  w = the conv's filter [cout][c] in compute precision (w_dtype).
  * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the two data-gradient passes
@@ -282,10 +280,13 @@ int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, in
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
                     float* shift, float* t, sfk_stream_t stream);
-int sfk_bn_tail_bwd(const float* r, const float* sdz, const float* gram, const float* t, int32_t c, int32_t gld,
-                    const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean,
-                    const float* invstd, float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias,
-                    float* coef, sfk_stream_t stream); /* r [cout][c], sdz [cout]; coef: [cout][4] fp32 scratch */
+int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, const float* gram, const float* t,
+                    int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma,
+                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* wd, void* ws,
+                    float* bias, float* coef, sfk_stream_t stream);
+/* r [cout][c]; dz_partials [nparts][cout][2], component 0 = partial sums of dz as the kernel that WROTE dz left them
+ * (sfk_bn_bwd_reduce with y == NULL, or the data-gradient pass with bnb.y_bn.ptr == NULL + out_relu_bits); coef: [cout][4]
+ * fp32 scratch */
 
 /* ---------------------------------------------------------------------------------------------------------
  * MaxPool3d (1,k,k)/(1,s,s)/(0,p,p) of the stems (my_slowfast.py:66-68).  `argmax` (uint8 per output

@@ -109,6 +109,14 @@ class EmuBackend:
                 m = ((b >> torch.arange(vec, dtype=torch.int32, device=b.device)) & 1).reshape(res.shape)
                 res = res * m.float()
             dest.copy_(res.to(Y.dtype))
+            if p.bnb is not None and p.bnb.y_bn is None:     # bitmap mask + per-tile partial sums of the STORED dz
+                flat = dest.float().reshape(-1, p.cout)
+                bm = _tile_bm(p.cout)
+                mt = (flat.shape[0] + bm - 1) // bm
+                st = p.bnb.partials[: mt * p.cout * 2].view(mt, p.cout, 2)
+                for i in range(mt):
+                    st[i, :, 0] = flat[i * bm:(i + 1) * bm].sum(0)
+                    st[i, :, 1] = 0
             if p.stats is not None:
                 flat = acc.reshape(-1, p.cout)
                 bm = _tile_bm(p.cout)
@@ -133,14 +141,6 @@ class EmuBackend:
         return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
 
     # ------------------------------------------------------------------ bottleneck tail (sfk_bn_tail_*, sfk_relu_bits_mask)
-    def relu_bits_mask(self, da: FMap, relu_bits, dz: FMap):
-        def run(stream):
-            vec = self._vec(da)
-            b = relu_bits[: da.pixels * (da.c // vec)].to(torch.int32).reshape(-1, da.c // vec, 1)
-            m = ((b >> torch.arange(vec, dtype=torch.int32)) & 1).reshape(da.n, da.t, da.h, da.w, da.c)
-            dz.view5().copy_((da.view5().float() * m.float()).to(dz.dtype))
-        return run
-
     def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, t):
         def run(stream):
             Gx = gram[: gld * gld].view(gld, gld).double()
@@ -164,10 +164,11 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
-    def bn_tail_bwd(self, r, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws,
+                    bias, coef):
         def run(stream):
             R = r[: cout * c].view(cout, c).double()
-            s_ = sdz[:cout].double()
+            s_ = dz_partials[: nparts * cout * 2].view(nparts, cout, 2)[:, :, 0].double().sum(0)
             Gx = gram[: gld * gld].view(gld, gld).double()
             g, n = Gx[c, :c], float(Gx[c, c])
             W = w[: cout * c].view(cout, c).double()
@@ -194,8 +195,6 @@ class EmuBackend:
             dw = p.dw[: p.cout * p.wtaps * p.cin].view(p.cout, p.wtaps, p.cin)
             for tap in p.taps:
                 dw[:, tap[3], :] += torch.einsum("nthwo,nthwc->oc", dY, _gather(X, rows, p.gs, tap))
-            if getattr(p, "sum_dy", None) is not None:
-                p.sum_dy[: p.cout].add_(dY.reshape(-1, p.cout).sum(0))
         return run
 
     @staticmethod
@@ -314,20 +313,24 @@ class EmuBackend:
     def bn_bwd_reduce(self, da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts,
                       relu_bits=None):
         def run(stream):
-            c = y.c
+            c = da.c
             if relu_bits is not None:
                 assert mask_src is None
-                vec = self._vec(y)
-                b = relu_bits[: y.pixels * (c // vec)].to(torch.int32).reshape(-1, c // vec, 1)
+                vec = self._vec(da)
+                b = relu_bits[: da.pixels * (c // vec)].to(torch.int32).reshape(-1, c // vec, 1)
                 m = ((b >> torch.arange(vec, dtype=torch.int32, device=b.device)) & 1).reshape(-1, c)
-                yv = y.view5().float()
-                dz = da.view5().float() * m.reshape(yv.shape).float()
+                dav = da.view5().float()
+                dz = dav * m.reshape(dav.shape).float()
+                yv = y.view5().float() if y is not None else None
             else:
                 dz, yv = self._dz(da, y, mask_src, scale, shift, relu)
-            xhat = (yv - mean[:c]) * invstd[:c]
             pt = partials[: c * 2].view(1, c, 2)
             pt[0, :, 0] = dz.reshape(-1, c).sum(0)
-            pt[0, :, 1] = (dz * xhat).reshape(-1, c).sum(0)
+            if yv is None:                      # y == NULL: the fused block tail's variant, (sum dz, 0)
+                pt[0, :, 1] = 0
+            else:
+                xhat = (yv - mean[:c]) * invstd[:c]
+                pt[0, :, 1] = (dz * xhat).reshape(-1, c).sum(0)
             if dz_out is not None:
                 dz_out.view5().copy_(dz.to(dz_out.dtype))
         return run, 1

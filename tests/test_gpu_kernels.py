@@ -701,3 +701,37 @@ def test_conv_epilogue_variants(hip, dtype):
     p = ConvPass(xg, yg, (1, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0), [(0, 0, 0, 0)], torch.zeros(64, dtype=torch.bfloat16, device=DEV),
                  1, 8, 8, ep=ConvEpilogue(shift=torch.zeros(8, device=DEV), relu=True))
     assert not hip.conv_epilogue_supported(p)            # ReLU needs two co fragments per wave in bf16 (cout > 16)
+
+
+def test_conv_masked_store_with_dz_sums_bf16(hip):
+    """sfk_bn_bwd_fuse with y_bn = NULL + out_relu_bits: the data-gradient pass that finishes a block's output gradient
+    stores dz = (old + result) * bitmap and leaves the per-tile partial sums of the STORED dz (what sfk_bn_tail_bwd folds)"""
+    from video_classification_amd._lib import BnBwdFuse
+    gen = torch.Generator().manual_seed(31)
+    emu = EmuBackend()
+    dtype = torch.bfloat16
+    for (n, t, h, w, cin, cout, k) in ((2, 2, 9, 7, 16, 40, (3, 1, 1)), (1, 3, 12, 12, 64, 256, (1, 1, 1)), (2, 2, 7, 7, 8, 32, (3, 1, 1))):
+        g = ConvGeom(cout, cin, k, (1, 1, 1), (k[0] // 2, 0, 0))            # forward conv cout -> cin; this is its dgrad
+        passes, _ = dgrad_passes(g, (t, h, w))
+        assert len(passes) == 1
+        sp = passes[0]
+        dyc, dyg = fmap_pair(n, cin, t, h, w, dtype, gen)
+        wt = mk((cout * g.wtaps * cin,), dtype, gen, 0.2)                   # [cin_g = cout][tap][cout_g = cin] as St
+        bits = torch.randint(0, 256, (n * t * h * w * cout // 8,), generator=gen, dtype=torch.uint8)
+        outs = []
+        for be, dy, dev, st in ((emu, dyc, "cpu", 0), (hip, dyg, DEV, stream())):
+            gen2 = torch.Generator().manual_seed(5)
+            dx = FMap(mk((n * t * h * w * cout,), dtype, gen2).to(dev), n, t, h, w, cout)        # the += target
+            p = ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(dev), g.wtaps, cin, cout, accumulate=True)
+            assert be is emu or (be.conv_relu_out_supported(p) and be.conv_bnb_supported(p))
+            mt = be.conv_igemm_mtiles(p)
+            parts = torch.full((mt * cout * 2,), 7.0, device=dev)
+            p.relu_out_bits = bits.to(dev)
+            p.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
+            be.conv_igemm(p)(st)
+            outs.append((dx.buf, parts.view(mt, cout, 2)))
+        torch.cuda.synchronize()
+        (xc, pc), (xg, pg) = outs
+        assert rel_err(xg.float().cpu(), xc.float()) < TOL[dtype]
+        assert rel_err(pg.sum(0)[:, 0].cpu(), pc.sum(0)[:, 0]) < 2e-3 and float(pg[:, :, 1].abs().max()) == 0.0
+        assert rel_err(pg.sum(0)[:, 0].cpu(), xg.float().cpu().view(-1, cout).sum(0)) < 1e-3     # sums of what was stored

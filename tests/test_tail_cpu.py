@@ -64,13 +64,15 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     be.conv_igemm(fwd)(stream)
     # ---- backward of sum(out * gout)
     dz = FMap(gout.to(dtype).to(dev).reshape(-1).contiguous(), n, t, h, w, cout)
-    be.relu_bits_mask(dz, bits, dz)(stream)
-    r, sdz = f32(cout * c), f32(cout)
-    be.conv_wgrad(WgradPass(av, dz, ONE, TAP0, r, 1, c, cout, sum_dy=sdz))(stream)
+    parts = f32(1024 * cout * 2)
+    run, nparts = be.bn_bwd_reduce(dz, None, None, None, None, None, None, True, dz, parts, 1024, relu_bits=bits)
+    run(stream)                                                          # dz *= mask (in place) and partial sums of dz
+    r = f32(cout * c)
+    be.conv_wgrad(WgradPass(av, dz, ONE, TAP0, r, 1, c, cout))(stream)
     dgamma, dbeta, dw, bias, coef = f32(cout), f32(cout), f32(cout * c), f32(c), f32(cout * 4)
     wd = torch.zeros(cout * c, dtype=dtype, device=dev)
     ws = torch.zeros(cout * c, dtype=dtype, device=dev)
-    be.bn_tail_bwd(r, sdz, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)(stream)
+    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)(stream)
     m32 = f32(c * c)
     wmap = FMap(wq, 1, 1, 1, cout, c)                                  # the filter as a [cout pixels][c] map
     be.conv_wgrad(WgradPass(wmap, FMap(ws, 1, 1, 1, cout, c), ONE, TAP0, m32, 1, c, c))(stream)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 6        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 7        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -74,10 +74,10 @@ Tap = Tuple[int, int, int, int]  # (dt, dh, dw, widx)
 @dataclass
 class BnBwdFuse:
     """sfk_bn_bwd_fuse: the BatchNorm-backward reduce folded into the data-gradient pass that produces dA."""
-    y_bn: FMap                       # conv output the BatchNorm normalised
+    y_bn: Optional[FMap]             # conv output the BatchNorm normalised; None (+ relu_out_bits): bitmap mask, sum dz only
     mask_src: Optional[FMap]         # activation whose sign is the ReLU mask, or None
-    mean: torch.Tensor
-    invstd: torch.Tensor
+    mean: Optional[torch.Tensor]
+    invstd: Optional[torch.Tensor]
     scale: Optional[torch.Tensor]
     shift: Optional[torch.Tensor]
     relu: bool
@@ -127,7 +127,6 @@ class WgradPass:
     cin: int
     cout: int
     workspace: Optional[torch.Tensor] = None   # fp32 scratch for the partial-tile path (sfk_conv_wgrad_workspace_bytes)
-    sum_dy: Optional[torch.Tensor] = None      # fp32 [cout]: += column sums of dy (sfk_wgrad_desc.sum_dy)
 
 
 @dataclass
@@ -177,7 +176,7 @@ class _ConvDesc(C.Structure):
 class _WgradDesc(C.Structure):
     _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("sum_dy", C.c_void_p)]
+                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class _StemSrc(C.Structure):
@@ -213,9 +212,8 @@ SIGNATURES = {
     "sfk_conv_bnb_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
-    "sfk_relu_bits_mask": [_P_FMAP, _PV, _P_FMAP, _PV],
     "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
-    "sfk_bn_tail_bwd": [_PF, _PF, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
+    "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
@@ -330,7 +328,8 @@ def _c_conv(p: ConvPass) -> _ConvDesc:
     d.stats = _ptr(p.stats)
     if p.bnb is not None:
         b = p.bnb
-        d.bnb.y_bn = _c_fmap(b.y_bn)
+        if b.y_bn is not None:
+            d.bnb.y_bn = _c_fmap(b.y_bn)
         if b.mask_src is not None:
             d.bnb.mask_src = _c_fmap(b.mask_src)
         d.bnb.mean, d.bnb.invstd = _ptr(b.mean), _ptr(b.invstd)
@@ -401,9 +400,6 @@ class HipBackend:
         d.gs = (C.c_int32 * 3)(*p.gs)
         d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)
         d.dw, d.wtaps, d.cin, d.cout = p.dw.data_ptr(), p.wtaps, p.cin, p.cout
-        if p.sum_dy is not None:
-            assert p.sum_dy.dtype == torch.float32 and p.sum_dy.numel() >= p.cout
-            d.sum_dy = p.sum_dy.data_ptr()
         return d
 
     def conv_wgrad_workspace_bytes(self, p: WgradPass) -> int:
@@ -515,18 +511,18 @@ class HipBackend:
                       dz_out: Optional[FMap], partials, max_parts, relu_bits=None):
         """returns (run, nparts); relu_bits: the mask bn_apply wrote (then mask_src must be None)."""
         if relu_bits is not None:
-            vec = 8 if y.dtype == torch.bfloat16 else 4
-            assert relu_bits.dtype == torch.uint8 and relu_bits.numel() >= y.pixels * (y.c // vec)
-        fa, fy = _c_fmap(da), _c_fmap(y)
+            vec = 8 if da.dtype == torch.bfloat16 else 4
+            assert relu_bits.dtype == torch.uint8 and relu_bits.numel() >= da.pixels * (da.c // vec)
+        fa, fy = _c_fmap(da), (_c_fmap(y) if y is not None else None)
         fm = _c_fmap(mask_src) if mask_src is not None else None
         fz = _c_fmap(dz_out) if dz_out is not None else None
         np_ = C.c_int32(0)
-        run = self._plain("sfk_bn_bwd_reduce", C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean),
+        run = self._plain("sfk_bn_bwd_reduce", C.byref(fa), C.byref(fy) if fy else None, C.byref(fm) if fm else None, _ptr(mean),
                           _ptr(invstd), _ptr(scale), _ptr(shift), 1 if relu else 0, C.byref(fz) if fz else None,
                           _ptr(partials), max_parts, C.byref(np_), _ptr(relu_bits),
                           keep=(fa, fy, fm, fz, np_, da, y, mask_src, dz_out, mean, invstd, scale, shift, partials,
                                 relu_bits))
-        return run, self._dry_parts(y, max_parts)
+        return run, self._dry_parts(da, max_parts)
 
     def bn_bwd_finalize(self, partials, nparts, c, count, gamma, invstd, dgamma, dbeta, coef, workspace=None):
         return self._plain("sfk_bn_bwd_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(invstd),
@@ -542,10 +538,6 @@ class HipBackend:
                            keep=(fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift, coef))
 
     # -- the bottleneck tail (conv_c -> norm_c without the conv output in HBM)
-    def relu_bits_mask(self, da: FMap, relu_bits, dz: FMap):
-        fa, fz = _c_fmap(da), _c_fmap(dz)
-        return self._plain("sfk_relu_bits_mask", C.byref(fa), _ptr(relu_bits), C.byref(fz), keep=(fa, fz, da, dz, relu_bits))
-
     def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
                     scale, shift, t):
         ts = (gram, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t)
@@ -553,11 +545,12 @@ class HipBackend:
                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
                            _ptr(scale), _ptr(shift), _ptr(t), keep=ts)
 
-    def bn_tail_bwd(self, r, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef):
-        ts = (r, sdz, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
-        return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(sdz), _ptr(gram), _ptr(t), c, gld, _ptr(w), _DT[w.dtype], cout,
-                           _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw), _ptr(wd), _ptr(ws),
-                           _ptr(bias), _ptr(coef), keep=ts)
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws,
+                    bias, coef):
+        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
+        return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(gram), _ptr(t), c, gld, _ptr(w),
+                           _DT[w.dtype], cout, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
+                           _ptr(wd), _ptr(ws), _ptr(bias), _ptr(coef), keep=ts)
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

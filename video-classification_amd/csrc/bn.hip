@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
 }
 
 // ------------------------------------------------------------------ backward
-// MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0), 3 mask = relu_bits of bn_apply
+// MASK: 0 none, 1 recompute ReLU mask from y*scale+shift, 2 mask = (mask_src > 0), 3 mask = relu_bits of bn_apply,
+//       4 = relu_bits and NO y: only dz = da * mask and sum dz (the fused block tail, sfk_bn_tail_bwd)
 template <typename T, int MASK, bool WRITE_DZ, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc, FM dzo, int64_t pixels, int c,
                                                             const float* mean, const float* invstd,
@@ -309,14 +310,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
   for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   if (cm.active) {
     float mu[VEC], is[VEC], sc[VEC], sh[VEC];
-    load_coef<VEC>(mu, mean, cm.cg);
-    load_coef<VEC>(is, invstd, cm.cg);
+    if (MASK != 4) {
+      load_coef<VEC>(mu, mean, cm.cg);
+      load_coef<VEC>(is, invstd, cm.cg);
+    }
     if (MASK == 1) {
       load_coef<VEC>(sc, scale, cm.cg);
       load_coef<VEC>(sh, shift, cm.cg);
     }
     const T* dap = static_cast<const T*>(da.p) + da.off + cm.cg * VEC;
-    const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+    const T* yp = MASK != 4 ? static_cast<const T*>(y.p) + y.off + cm.cg * VEC : nullptr;
     const T* mp = MASK == 2 ? static_cast<const T*>(msrc.p) + msrc.off + cm.cg * VEC : nullptr;
     T* zp = WRITE_DZ ? static_cast<T*>(dzo.p) + dzo.off + cm.cg * VEC : nullptr;
     constexpr int U = SFK_BN_U;                     // spans of U * rows_b consecutive rows, block b: spans b, b + G, ...
@@ -331,14 +334,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
         const int64_t pc = p < pend ? p : p0;          // past the end: re-read row p0 (neither summed nor stored)
         if (nt & 2) {
           d[u].load_nt(dap + pc * da.ld);
-          v[u].load_nt(yp + pc * y.ld);
+          if (MASK != 4) v[u].load_nt(yp + pc * y.ld);
         } else {
           d[u].load(dap + pc * da.ld);
-          v[u].load(yp + pc * y.ld);
+          if (MASK != 4) v[u].load(yp + pc * y.ld);
         }
         if (MASK == 2) m[u].load(mp + pc * msrc.ld);
         bits[u] = 0;
-        if (MASK == 3) bits[u] = relu_bits[pc * cgs + cm.cg];
+        if (MASK >= 3) bits[u] = relu_bits[pc * cgs + cm.cg];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -347,14 +350,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
         Vec16<T> z;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          const float yv = v[u].get(i);
+          const float yv = MASK != 4 ? v[u].get(i) : 0.f;
           float dz = d[u].get(i);
           if (MASK == 1) dz = (yv * sc[i] + sh[i] > 0.f) ? dz : 0.f;
           if (MASK == 2) dz = (m[u].get(i) > 0.f) ? dz : 0.f;
-          if (MASK == 3) dz = ((bits[u] >> i) & 1u) ? dz : 0.f;
+          if (MASK >= 3) dz = ((bits[u] >> i) & 1u) ? dz : 0.f;
           if (WRITE_DZ) z.set(i, dz);
           s1[i] += dz;
-          s2[i] += dz * ((yv - mu[i]) * is[i]);
+          if (MASK != 4) s2[i] += dz * ((yv - mu[i]) * is[i]);
         }
         if (WRITE_DZ) {
           if (nt & 1) z.store_nt(zp + p * dzo.ld);
@@ -550,18 +553,20 @@ int launch_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms,
                       const float* invstd, const float* scale, const float* shift, int relu,
                       const sfk_fmap* dzo, float* partials, int max_parts, int* nparts_out, const uint8_t* bits,
                       hipStream_t s) {
-  const int64_t px = sfk_fmap_pixels(y);
+  const int64_t px = sfk_fmap_pixels(da);
   int np;
-  const dim3 grid = chan_grid(y->c / DT<T>::VEC, px, max_parts, &np), blk(256);
+  const dim3 grid = chan_grid(da->c / DT<T>::VEC, px, max_parts, &np), blk(256);
   const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), z = fm_of(dzo);
-  const int mask = bits ? 3 : (ms ? 2 : (relu ? 1 : 0));
-  const int nt = nt_hint(y, sfk_tune().nt_reduce_mb, 2);
+  const int mask = bits ? (y ? 3 : 4) : (ms ? 2 : (relu ? 1 : 0));
+  const int nt = nt_hint(da, sfk_tune().nt_reduce_mb, 2);
 #define SFK_RED(M, W)                                                                                                        \
   do {                                                                                                                     \
-    if (nt) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 2>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits); \
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 0>), grid, blk, 0, s, a, b, m, z, px, y->c, mean, invstd, scale, shift, partials, bits);    \
+    if (nt) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 2>), grid, blk, 0, s, a, b, m, z, px, da->c, mean, invstd, scale, shift, partials, bits); \
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M, W, 0>), grid, blk, 0, s, a, b, m, z, px, da->c, mean, invstd, scale, shift, partials, bits);    \
   } while (0)
-  if (dzo) {
+  if (mask == 4) {
+    if (dzo) SFK_RED(4, true); else SFK_RED(4, false);
+  } else if (dzo) {
     if (mask == 0) SFK_RED(0, true); else if (mask == 1) SFK_RED(1, true); else if (mask == 2) SFK_RED(2, true); else SFK_RED(3, true);
   } else {
     if (mask == 0) SFK_RED(0, false); else if (mask == 1) SFK_RED(1, false); else if (mask == 2) SFK_RED(2, false); else SFK_RED(3, false);
@@ -601,14 +606,19 @@ extern "C" int sfk_bn_bwd_reduce(const sfk_fmap* da, const sfk_fmap* y, const sf
                                  const sfk_fmap* dz_out, float* partials, int32_t max_parts, int32_t* nparts_out,
                                  const uint8_t* relu_bits, sfk_stream_t stream) {
   if (relu_bits && mask_src) return SFK_ERR_INVALID;
-  const int st = check_bwd(da, y, mask_src, mean, invstd, (relu_bits ? nullptr : scale), (relu_bits ? nullptr : shift),
-                           relu_bits ? 0 : relu);
-  if (st != SFK_OK) return st;
+  if (!y) {        // mask + sum dz only (the fused block tail): needs the bitmap
+    if (!relu_bits || !sfk_fmap_ok(da)) return SFK_ERR_INVALID;
+    if (!sfk_fmap_vec_ok(da)) return SFK_ERR_UNSUPPORTED;
+  } else {
+    const int st = check_bwd(da, y, mask_src, mean, invstd, (relu_bits ? nullptr : scale), (relu_bits ? nullptr : shift),
+                             relu_bits ? 0 : relu);
+    if (st != SFK_OK) return st;
+  }
   if (!partials || max_parts <= 0 || !nparts_out) return SFK_ERR_INVALID;
   if (dz_out && (!sfk_fmap_ok(dz_out) || !same_shape(da, dz_out))) return SFK_ERR_INVALID;
   if (dz_out && !sfk_fmap_vec_ok(dz_out)) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return y->dtype == SFK_BF16
+  return da->dtype == SFK_BF16
              ? launch_bwd_reduce<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, relu_bits, s)
              : launch_bwd_reduce<float>(da, y, mask_src, mean, invstd, scale, shift, relu, dz_out, partials, max_parts, nparts_out, relu_bits, s);
 }

@@ -3,7 +3,7 @@
 //
 // What the big kernels deliver (ordinary sfk_conv_wgrad calls over `a` widened by a constant-1 channel):
 //     gram [c+V][c+V] fp32 : G = a^T a, row c = column sums g, element (c,c) = pixel count n
-//     r    [cout][c] fp32  : R = dz^T a, and sdz [cout] = s = sum dz (sfk_wgrad_desc.sum_dy of the same call)
+//     r    [cout][c] fp32  : R = dz^T a;  s = sum dz arrives as the partial rows of the kernel that wrote dz
 // What this file computes from them -- everything is O(cout * c^2) or less, i.e. independent of the pixel count:
 //     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift
 //     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the two data-gradient passes
@@ -109,20 +109,24 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
 
 // one wave per output channel: sum dz*y = W[co] . R[co]; coefficients of dy = A dz + B y + C; dgamma, dbeta
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ sdz,
-                                                           const float* __restrict__ gram, int c, int gld, const void* w,
-                                                           int cout, const float* gamma,
+__global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ parts,
+                                                           int nparts, const float* __restrict__ gram, int c, int gld,
+                                                           const void* w, int cout, const float* gamma,
                                                            const float* mean, const float* invstd, float* dgamma,
                                                            float* dbeta, float* coef) {
   const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (co >= cout) return;
   double sdy = 0.0;
   for (int ci = lane; ci < c; ci += 64) sdy += (double)wload<D>(w, (int64_t)co * c + ci) * (double)rx[(int64_t)co * c + ci];
+  double s = 0.0;                                          // sum dz: the partial rows [nparts][cout][2], component 0
+  for (int p = lane; p < nparts; p += 64) s += (double)parts[((int64_t)p * cout + co) * 2];
 #pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) sdy += __shfl_xor(sdy, sft);
+  for (int sft = 1; sft < 64; sft <<= 1) {
+    sdy += __shfl_xor(sdy, sft);
+    s += __shfl_xor(s, sft);
+  }
   if (lane != 0) return;
   const double n = (double)gram[(int64_t)c * gld + c];
-  const double s = (double)sdz[co];
   const double is = (double)invstd[co], mu = (double)mean[co];
   const double sxh = is * (sdy - mu * s);                 // sum dz * x_hat
   dgamma[co] += (float)sxh;
@@ -187,24 +191,6 @@ __global__ __launch_bounds__(256) void bn_tail_bias_kernel(const void* w, int c,
   }
 }
 
-// dz = da * mask(bitmap): 16 bytes per thread, one bitmap byte each
-template <typename T>
-__global__ __launch_bounds__(256) void relu_bits_mask_kernel(const T* da, int dld, int doff, T* dz, int zld, int zoff,
-                                                             const uint8_t* __restrict__ bits, int64_t groups, int cgs) {
-  constexpr int VEC = DT<T>::VEC;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < groups; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / cgs;
-    const int cg = (int)(i - p * cgs);
-    Vec16<T> v;
-    v.load(da + p * dld + doff + cg * VEC);
-    const uint32_t b = bits[i];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e)
-      if (!((b >> e) & 1u)) v.set(e, 0.f);
-    v.store(dz + p * zld + zoff + cg * VEC);
-  }
-}
-
 inline bool tail_args_ok(int c, int gld, int cout, int dtype) {
   return c > 0 && cout > 0 && gld > c && (dtype == SFK_F32 || dtype == SFK_BF16);
 }
@@ -231,10 +217,10 @@ extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const 
 }
 
 template <typename D>
-static int tail_bwd_launch(const float* rx, const float* sdz, const float* gram, const float* t, int c, int gld, const void* w, int cout,
+static int tail_bwd_launch(const float* rx, const float* parts, int nparts, const float* gram, const float* t, int c, int gld, const void* w, int cout,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                            float* dw, void* wd, void* ws, float* bias, float* coef, hipStream_t s) {
-  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, sdz, gram, c, gld, w, cout, gamma, mean,
+  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, parts, nparts, gram, c, gld, w, cout, gamma, mean,
                      invstd, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_tail_apply_kernel<D>, dim3((c + 31) / 32, (cout + 31) / 32), dim3(256), 0, s, rx, gram, t, c, gld,
                      w, cout, coef, dw, static_cast<D*>(wd), static_cast<D*>(ws));
@@ -243,34 +229,15 @@ static int tail_bwd_launch(const float* rx, const float* sdz, const float* gram,
   return SFK_OK;
 }
 
-extern "C" int sfk_bn_tail_bwd(const float* rx, const float* sdz, const float* gram, const float* t, int32_t c, int32_t gld,
-                               const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
+extern "C" int sfk_bn_tail_bwd(const float* rx, const float* parts, int32_t nparts, const float* gram, const float* t,
+                               int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
                                float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
                                sfk_stream_t stream) {
-  if (!rx || !sdz || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
+  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
     return SFK_ERR_INVALID;
   if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return w_dtype == SFK_BF16
-             ? tail_bwd_launch<bf16_t>(rx, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
-             : tail_bwd_launch<float>(rx, sdz, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
-}
-
-extern "C" int sfk_relu_bits_mask(const sfk_fmap* da, const uint8_t* relu_bits, const sfk_fmap* dz, sfk_stream_t stream) {
-  if (!sfk_fmap_ok(da) || !sfk_fmap_ok(dz) || !relu_bits) return SFK_ERR_INVALID;
-  if (da->dtype != dz->dtype || da->c != dz->c || sfk_fmap_pixels(da) != sfk_fmap_pixels(dz)) return SFK_ERR_INVALID;
-  if (!sfk_fmap_vec_ok(da) || !sfk_fmap_vec_ok(dz)) return SFK_ERR_UNSUPPORTED;
-  const int vec = sfk_vec_of(da->dtype), cgs = da->c / vec;
-  const int64_t groups = sfk_fmap_pixels(da) * cgs;
-  int64_t blocks = (groups + 255) / 256;
-  if (blocks > (1 << 20)) blocks = 1 << 20;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (da->dtype == SFK_BF16)
-    hipLaunchKernelGGL(relu_bits_mask_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const bf16_t*>(da->ptr),
-                       da->ld, da->c_off, static_cast<bf16_t*>(dz->ptr), dz->ld, dz->c_off, relu_bits, groups, cgs);
-  else
-    hipLaunchKernelGGL(relu_bits_mask_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(da->ptr),
-                       da->ld, da->c_off, static_cast<float*>(dz->ptr), dz->ld, dz->c_off, relu_bits, groups, cgs);
-  SFK_CHECK_LAUNCH();
-  return SFK_OK;
+             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
+             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
 }

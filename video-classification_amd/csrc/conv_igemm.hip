@@ -45,6 +45,7 @@ struct ConvK {
   FastDiv dspt;   // 16-byte channel segments per tap (cin / VEC)
   FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
+  uint32_t ybytes, ep_rbytes; // ... and of y / the shortcut map (fused epilogue: branch-free loads)
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -179,6 +180,7 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
   const bf16_t* __restrict__ by = static_cast<const bf16_t*>(k.bn_y);
   const bf16_t* __restrict__ bm = static_cast<const bf16_t*>(k.bn_mask);
+  const bool bitmode = by == nullptr;     // mask = the output ReLU bitmap k.obits, only sum dz is left (fused block tail)
   const int co_w = nt * BN + wn * (BN / WN);
 #pragma unroll
   for (int p = 0; p < FN; p += 2) {
@@ -188,11 +190,11 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cok ? co + e : 0;
-      const float is = k.bn_invstd[c];
+      const float is = bitmode ? 0.f : k.bn_invstd[c];
       ca[e] = is;
-      cb[e] = -k.bn_mean[c] * is;                                   // x_hat = y * ca + cb
-      cs[e] = (k.bn_relu && !bm) ? k.bn_scale[c] : 0.f;
-      ch[e] = (k.bn_relu && !bm) ? k.bn_shift[c] : 1.f;             // no mask: y*0 + 1 > 0
+      cb[e] = bitmode ? 0.f : -k.bn_mean[c] * is;                   // x_hat = y * ca + cb
+      cs[e] = (k.bn_relu && !bm && !bitmode) ? k.bn_scale[c] : 0.f;
+      ch[e] = (k.bn_relu && !bm && !bitmode) ? k.bn_shift[c] : 1.f; // no mask: y*0 + 1 > 0
     }
     float s1[8], s2[8];
 #pragma unroll
@@ -223,14 +225,16 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
           }
-          const bf16x8 yv = *reinterpret_cast<const bf16x8*>(by + plin * k.bn_yld + k.bn_yoff + co);
+          bf16x8 yv = {};
+          if (!bitmode) yv = *reinterpret_cast<const bf16x8*>(by + plin * k.bn_yld + k.bn_yoff + co);
           bf16x8 mv;
           if (bm) mv = *reinterpret_cast<const bf16x8*>(bm + plin * k.bn_mld + k.bn_moff + co);
+          const uint32_t mbyte = bitmode ? k.obits[plin * (k.cout >> 3) + (co >> 3)] : 0u;
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float yf = (float)yv[e];
-            const bool keep = bm ? ((float)mv[e] > 0.f) : (yf * cs[e] + ch[e] > 0.f);
+            const bool keep = bitmode ? ((mbyte >> e) & 1u) : (bm ? ((float)mv[e] > 0.f) : (yf * cs[e] + ch[e] > 0.f));
             // dz is what the BatchNorm backward sees: the value as it is STORED (bf16), masked
             const bf16_t dzb = (bf16_t)(keep ? v[e] : 0.f);
             const float dz = (float)dzb;
@@ -295,13 +299,35 @@ __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc
       const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
       const bool cok = co < k.cout;
       const int cc = cok ? co : 0;
+      // per-channel coefficients: 16-byte BUFFER loads -- an absent vector is a zero-sized resource that reads zeros, so
+      // nothing is loaded under a branch (a conditional load makes hipcc drain vmcnt behind it: eight serial round trips
+      // per tile measured +53 us on a 411 MB map; one scalar load per channel, 48 of them, +66 us)
       float sc[8], sh[8], rs[8];
+      {
+        const uint32_t cb = (uint32_t)cc * 4u, nb = (uint32_t)k.cout * 4u;
+        const __amdgpu_buffer_rsrc_t r_sc = sfk_make_rsrc(k.ep_scale, k.ep_scale ? nb : 0u);
+        const __amdgpu_buffer_rsrc_t r_sh = sfk_make_rsrc(k.ep_shift, k.ep_shift ? nb : 0u);
+        const __amdgpu_buffer_rsrc_t r_rs = sfk_make_rsrc(k.ep_rscale, (rp && k.ep_rscale) ? nb : 0u);
+        const __amdgpu_buffer_rsrc_t r_rh = sfk_make_rsrc(k.ep_rshift, (rp && k.ep_rshift) ? nb : 0u);
+        const uint4 a0 = sfk_buffer_load16(r_sc, cb), a1 = sfk_buffer_load16(r_sc, cb + 16);
+        const uint4 b0 = sfk_buffer_load16(r_sh, cb), b1 = sfk_buffer_load16(r_sh, cb + 16);
+        const uint4 c0 = sfk_buffer_load16(r_rh, cb), c1 = sfk_buffer_load16(r_rh, cb + 16);
+        const uint4 d0 = sfk_buffer_load16(r_rs, cb), d1 = sfk_buffer_load16(r_rs, cb + 16);
+        const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const uint32_t cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const uint32_t dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const bool has_sc = k.ep_scale != nullptr, has_rs = rp && k.ep_rscale;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sc[e] = k.ep_scale ? k.ep_scale[cc + e] : 1.f;
-        sh[e] = (k.ep_shift ? k.ep_shift[cc + e] : 0.f) + ((rp && k.ep_rshift) ? k.ep_rshift[cc + e] : 0.f);
-        rs[e] = (rp && k.ep_rscale) ? k.ep_rscale[cc + e] : 1.f;
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = has_sc ? __uint_as_float(av[e]) : 1.f;
+          sh[e] = __uint_as_float(bv[e]) + __uint_as_float(cv[e]);
+          rs[e] = has_rs ? __uint_as_float(dv[e]) : 1.f;
+        }
       }
+      // old values (+=) and the shortcut: buffer loads as well; absent -> zero-sized resource -> zeros
+      const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
+      const __amdgpu_buffer_rsrc_t r_res = sfk_make_rsrc(k.ep_res, rp ? k.ep_rbytes : 0u);
       // two pixel rows at a time: the 256x128 tile sits at its 128-VGPR cap, 2 x (old, shortcut) x 16 B is what fits
       constexpr int JB = FM >= 2 ? 2 : 1;
 #pragma unroll
@@ -310,8 +336,10 @@ __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
           const int j = j0 + jj;
-          if (k.accumulate) oldv[jj] = *reinterpret_cast<const bf16x8*>(yp + rows[j] * k.yld + k.yoff + cc);
-          if (rp) resv[jj] = *reinterpret_cast<const bf16x8*>(rp + rows[j] * k.ep_rld + k.ep_roff + cc);
+          const uint4 o4 = sfk_buffer_load16(r_old, (uint32_t)((rows[j] * k.yld + k.yoff + cc) * 2));
+          const uint4 r4 = sfk_buffer_load16(r_res, (uint32_t)((rows[j] * k.ep_rld + k.ep_roff + cc) * 2));
+          oldv[jj] = __builtin_bit_cast(bf16x8, o4);
+          resv[jj] = __builtin_bit_cast(bf16x8, r4);
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
@@ -325,9 +353,7 @@ __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float f = v[e] * sc[e] + sh[e];
-            if (k.accumulate) f += (float)oldv[jj][e];
-            if (rp) f += (float)resv[jj][e] * rs[e];
+            float f = v[e] * sc[e] + sh[e] + (float)oldv[jj][e] + (float)resv[jj][e] * rs[e];
             if (k.ep_relu) {
               bits |= (f > 0.f ? 1u : 0u) << e;
               f = f > 0.f ? f : 0.f;
@@ -1016,8 +1042,9 @@ int validate(const sfk_conv_desc* d) {
   if (!sfk_fmap_vec_ok(&d->x)) return SFK_ERR_UNSUPPORTED;
   if ((d->y.c % 4) || (d->y.ld % 4) || (d->y.c_off % 4) || (((uintptr_t)d->y.ptr) & 15)) return SFK_ERR_UNSUPPORTED;
   if (((uintptr_t)d->w) & 15) return SFK_ERR_UNSUPPORTED;
+  const bool bnb_bits = d->bnb.partials && !d->bnb.y_bn.ptr;   // mask = out_relu_bits, partials = (sum dz, 0)
   if (d->out_relu_bits) {
-    if (d->bnb.partials) return SFK_ERR_INVALID;
+    if (d->bnb.partials && !bnb_bits) return SFK_ERR_INVALID;
     if (!relu_out_ok(d)) return SFK_ERR_UNSUPPORTED;
   }
   if (ep_on(d)) {
@@ -1028,14 +1055,21 @@ int validate(const sfk_conv_desc* d) {
                       e.res.w != d->y.w || e.res.c != d->y.c || e.res.dtype != d->y.dtype))
       return SFK_ERR_INVALID;
     if (!lin_out_of(d)) return SFK_ERR_UNSUPPORTED;
+    if ((((uintptr_t)e.scale) | ((uintptr_t)e.shift) | ((uintptr_t)e.res_scale) | ((uintptr_t)e.res_shift)) & 15)
+      return SFK_ERR_UNSUPPORTED;
     if (d->x.dtype == SFK_BF16) {
       // tiles with an even number of co fragments (cout > 16) store 16-byte channel groups; the one-fragment tile of the
       // narrowest layers does scale / shift / += only
       if (d->cout > 16 ? !bnb_ok(d) : (e.res.ptr || e.relu)) return SFK_ERR_UNSUPPORTED;
     }
     if (e.res.ptr && !sfk_fmap_vec_ok(&e.res)) return SFK_ERR_UNSUPPORTED;
+    if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64 || (e.res.ptr && sfk_fmap_bytes(&e.res) >= (1ll << 32) - 64))
+      return SFK_ERR_UNSUPPORTED;
   }
-  if (d->bnb.partials) {
+  if (bnb_bits) {
+    if (!d->out_relu_bits || d->stats || d->bnb.mask_src.ptr) return SFK_ERR_INVALID;
+    if (!bnb_ok(d) || !lin_out_of(d)) return SFK_ERR_UNSUPPORTED;
+  } else if (d->bnb.partials) {
     const sfk_bn_bwd_fuse& b = d->bnb;
     if (d->stats || !sfk_fmap_ok(&b.y_bn) || !b.mean || !b.invstd) return SFK_ERR_INVALID;
     if (b.y_bn.n != d->y.n || b.y_bn.t != d->y.t || b.y_bn.h != d->y.h || b.y_bn.w != d->y.w || b.y_bn.c != d->y.c ||
@@ -1100,6 +1134,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.accumulate = d->accumulate;
   k.obits = d->out_relu_bits;
   k.bn_parts = d->bnb.partials;
+  k.bn_y = nullptr; k.bn_mask = nullptr;
   if (k.bn_parts) {
     k.bn_y = d->bnb.y_bn.ptr; k.bn_yld = d->bnb.y_bn.ld; k.bn_yoff = d->bnb.y_bn.c_off;
     k.bn_mask = d->bnb.mask_src.ptr; k.bn_mld = d->bnb.mask_src.ld; k.bn_moff = d->bnb.mask_src.c_off;
@@ -1110,6 +1145,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.ep_scale = d->ep.scale; k.ep_shift = d->ep.shift; k.ep_rscale = d->ep.res_scale; k.ep_rshift = d->ep.res_shift;
   k.ep_res = d->ep.res.ptr; k.ep_rld = d->ep.res.ld; k.ep_roff = d->ep.res.c_off;
   k.ep_relu = d->ep.relu; k.ep_bits = d->ep.relu_bits;
+  k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
+  k.ep_rbytes = d->ep.res.ptr ? (uint32_t)sfk_fmap_bytes(&d->ep.res) : 0u;
   k.kshort = sfk_tune().igemm_short_k;
   k.lin_out = lin_out_of(d);
   const int wide_ok = sfk_tune().igemm_wide_store;

@@ -29,7 +29,6 @@ struct WgradK {
   FastDiv dspt, dcin;             // 16-byte segments per tap; channels per tap
   uint32_t xbytes, dbytes;        // extents of the buffer resources
   float4* ws;                     // partial-tile workspace (NULL: fp32 atomics straight into dw)
-  float* sum_dy;                  // optional [cout]: += sum over pixels of dY (an extra MFMA against a ones operand)
   int ntiles;                     // cotiles * citiles
   sfk_tap taps[SFK_MAX_TAPS];
 };
@@ -81,18 +80,6 @@ template <int TC> struct WT<bf16_t, TC> {
   }
 };
 struct F32Frag { float v[8]; };
-__device__ __forceinline__ bf16x8 ones_frag(const bf16x8&) {
-  bf16x8 f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = (bf16_t)1.f;
-  return f;
-}
-__device__ __forceinline__ F32Frag ones_frag(const F32Frag&) {
-  F32Frag f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) f.v[e] = 1.f;
-  return f;
-}
 template <int TC> struct WT<float, TC> {
   static constexpr int VEC = 4, SEGS = TC / 4, ROWB = TC * 4 + 16;
   typedef F32Frag frag;
@@ -114,8 +101,7 @@ template <int TC> struct WT<float, TC> {
 // Block tile: TCO output channels x TCI columns of the flattened (tap, cin) axis; 4 waves as 2 x 2.  A stage is
 // KS K-steps (KS*32 pixels) between two barriers.  Column segments (16 B) are gathered independently, so a tile may
 // straddle taps and narrow layers put ALL their taps into one tile (9 x 8 channels = 72 columns).
-// SUMS: also accumulate sum_pixels dY per output channel (k.sum_dy), by the waves / blocks of the first column tile
-template <typename T, int TCO, int TCI, int KS, bool SUMS = false>
+template <typename T, int TCO, int TCI, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   using WO = WT<T, TCO>;
   using WI = WT<T, TCI>;
@@ -221,12 +207,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   for (int i = 0; i < FO; ++i)
 #pragma unroll
     for (int j = 0; j < FI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 accs[SUMS ? FO : 1];
-  const bool do_sum = SUMS && cit == 0 && wci == 0;
-  if constexpr (SUMS) {
-#pragma unroll
-    for (int i = 0; i < FO; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 
   gload(stage0);
   lstore(0);
@@ -248,27 +228,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
       for (int i = 0; i < FO; ++i)
 #pragma unroll
         for (int j = 0; j < FI; ++j) WO::mma(acc[i][j], a[i], b[j]);
-      if constexpr (SUMS) {
-        if (do_sum) {
-          const typename WO::frag one = ones_frag(a[0]);
-#pragma unroll
-          for (int i = 0; i < FO; ++i) WO::mma(accs[i], a[i], one);
-        }
-      }
     }
     lstore(buf ^ 1);
     __syncthreads();
-  }
-  if constexpr (SUMS) {   // every column of the ones product holds the same sum: column 0's lanes add it
-    if (do_sum && (lane & 15) == 0) {
-#pragma unroll
-      for (int i = 0; i < FO; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cot * TCO + wco * (TCO / 2) + 16 * i + 4 * (lane >> 4) + r;
-          if (co < k.cout) atomicAdd(k.sum_dy + co, accs[i][r]);
-        }
-    }
   }
 
   if (k.ws) {   // partial tile as it lies in the accumulators: 1 KiB per wave-instruction, summed by wgrad_reduce_kernel
@@ -313,7 +275,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
 
-template <int TCO, int NW, bool SUMS = false>
+template <int TCO, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_kernel(const WgradK k) {
   constexpr int TCI = 128, R = MK;
   constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
@@ -414,12 +376,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 accs[SUMS ? 4 : 1];
-  const bool do_sum = SUMS && cit == 0 && wci == 0;
-  if constexpr (SUMS) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 
   // transpose-read addresses (loop-invariant): lane (g, q, p) reads row 8g+q (+4), channels c0+4p..+3
   const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
@@ -462,13 +418,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    if constexpr (SUMS) {
-      if (do_sum) {
-        const bf16x8 one = ones_frag(a[0]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], one, accs[i], 0, 0, 0);
-      }
-    }
   };
   // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
   // (see conv_igemm.hip ring_wait)
@@ -493,17 +442,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if constexpr (SUMS) {
-    if (do_sum && (lane & 15) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cot * TCO + wco * 64 + 16 * i + 4 * (lane >> 4) + r;
-          if (co < k.cout) atomicAdd(k.sum_dy + co, accs[i][r]);
-        }
-    }
-  }
   if (k.ws) {
     float4* wp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * NW + wave) * 16) * 64 + lane;
 #pragma unroll
@@ -608,12 +546,7 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   k.ntiles = base;
   if (dry) { *dry = (int64_t)splits * base * NW * 16 * 64 * 16; return SFK_OK; }
   if (k.ws && (int64_t)splits * base * NW * 16 * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
-  if constexpr (NW == 4) {
-    if (k.sum_dy) hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, true>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
-    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
-  } else {
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
-  }
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<NW, TCO / 64, 4, 4>(k, splits, s);
   return SFK_OK;
@@ -655,8 +588,7 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   constexpr int FO = TCO / 32, FI = TCI / 32;
   if (dry) { *dry = (int64_t)splits * base * 4 * FO * FI * 64 * 16; return SFK_OK; }
   if (k.ws && (int64_t)splits * base * 4 * FO * FI * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
-  if (k.sum_dy) hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS, true>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<4, 2, FO, FI>(k, splits, s);
   return SFK_OK;
@@ -665,7 +597,7 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
 template <typename T>
 int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   WgradK k;
-  k.x = d->x.ptr; k.dy = d->dy.ptr; k.dw = d->dw; k.sum_dy = d->sum_dy;
+  k.x = d->x.ptr; k.dy = d->dy.ptr; k.dw = d->dw;
   k.xt = d->x.t; k.xh = d->x.h; k.xw = d->x.w; k.xld = d->x.ld; k.xoff = d->x.c_off;
   k.dld = d->dy.ld; k.doff = d->dy.c_off;
   k.M = (int)sfk_fmap_pixels(&d->dy);
@@ -682,8 +614,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   const int cols = d->ntaps * d->cin;
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
-    // (with sum_dy the 8-wave tile spills at its 128-VGPR cap: those calls take the 4-wave tile)
-    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24) && !d->sum_dy) return launch_dma<256, 8>(k, d, s, dry);
+    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s, dry);
     return launch_dma<128, 4>(k, d, s, dry);
   }
   if constexpr (sizeof(T) == 2) {

@@ -463,7 +463,8 @@ class Engine:
         pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
         pl.bwd.cur_lane = home
 
-    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None, out_bits=None):
+    def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None, out_bits=None,
+               out_sum_tag=None):
         """data gradient of rec's conv: dy -> dx (+= when accumulate).
         fuse = (bn unit whose activation gradient dx is, mask_src | None, relu, tag): fold that unit's BatchNorm-backward
         reduce into this pass's epilogue when the backend can (single stride-1 pass, bf16, > 16 channels); returns
@@ -491,6 +492,18 @@ class Engine:
                 cp.bnb = BnBwdFuse(brec.y, mask_src, brec.mean, brec.invstd, brec.scale, brec.shift, relu, parts)
                 reduced = (parts, mt)
                 extra = float(esz * rows * L.eg.cin * (2 if mask_src is not None else 1))
+            elif out_sum_tag is not None:
+                # dx is the output gradient of a block with a fused tail: its backward wants dz AND sum dz.  One pass that can
+                # (bitmap mask + per-tile sums in the epilogue: sfk_bn_bwd_fuse with y_bn = NULL) does both; otherwise dx
+                # stays unmasked and that block's own mask pass (sfk_bn_bwd_reduce, y = NULL) does it
+                if out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp) \
+                        and self.be.conv_bnb_supported(cp):
+                    mt = self.be.conv_igemm_mtiles(cp)
+                    parts = self._buf(f"bparts.{out_sum_tag}.c", max(mt, self.max_parts) * L.eg.cin * 2, torch.float32)
+                    cp.relu_out_bits = out_bits
+                    cp.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
+                    reduced = ("masked+sum", parts, mt)
+                    extra = float(rows * L.eg.cin // self.kvec)
             elif out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp):
                 cp.relu_out_bits = out_bits
                 reduced = "masked"
@@ -655,7 +668,7 @@ class Engine:
                     if self._tail_ok(Lc):
                         c4, C = Lc.eg.cin, Lc.eg.cout
                         nf += round_up((c4 + V) ** 2, 64)
-                        nb += round_up(C * c4, 64) + round_up(C, 64) + round_up(c4 * c4, 64)
+                        nb += round_up(C * c4, 64) + round_up(c4 * c4, 64)
         self._tailz = {"f": self._buf("tailz.f", nf, torch.float32)[:nf] if (train and nf) else None,
                        "b": self._buf("tailz.b", nb, torch.float32)[:nb] if (train and nb) else None}
         self._tailz_off = {"f": 0, "b": 0}
@@ -665,15 +678,15 @@ class Engine:
         self._tailz_off[key] = off + round_up(numel, 64)
         return self._tailz[key][off:off + numel]
 
-    def _tail_bwd(self, pl, Lc: _Layer, tail: dict, d_out: FMap, dab: FMap, tag: str):
+    def _tail_bwd(self, pl, Lc: _Layer, tail: dict, d_out: FMap, dab: FMap, tag: str, dz_parts):
         """dz (in d_out) -> dgamma, dbeta, dW of conv_c / norm_c and d(a_b) in dab, without y_c or dy_c:
-        R = dz^T a_b (and s = sum dz from the same call), the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
+        R = dz^T a_b, s = sum dz as the partial rows dz_parts = (rows, count) of the kernel that wrote dz, the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
         c4, C, gld = Lc.eg.cin, Lc.eg.cout, tail["gld"]
         full, ab = tail["full"], tail["ab"]
         esz = 2 if self.dtype == torch.bfloat16 else 4
         w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
-        r, sdz = self._tail_zero("b", C * c4), self._tail_zero("b", C)
-        wp = WgradPass(ab, d_out, (1, 1, 1), self.TAP0, r, 1, c4, C, sum_dy=sdz)
+        r = self._tail_zero("b", C * c4)
+        wp = WgradPass(ab, d_out, (1, 1, 1), self.TAP0, r, 1, c4, C)
         meta = dict(kind="conv_wgrad", layer=Lc.cb.conv_key, cout=C, flops=2.0 * d_out.pixels * C * c4,
                     bytes=float(esz * (ab.pixels * c4 + d_out.pixels * C) + 4 * C * c4))
         if self.deterministic_wgrad:
@@ -684,7 +697,7 @@ class Engine:
         ws = self._buf(f"tailWs.{tag}", C * c4)
         bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
         coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
-        pl.bwd.append(self.be.bn_tail_bwd(r, sdz, tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
+        pl.bwd.append(self.be.bn_tail_bwd(r, dz_parts[0], dz_parts[1], tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
                                           tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
                                           self._gslice(Lc.w_off, Lc.w_numel), wd, ws, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
@@ -748,12 +761,18 @@ class Engine:
         n = x.n
         dab = self._fmap(f"da.{tag}.b", n, recb.y.t, recb.y.h, recb.y.w, recb.y.c)
         if isinstance(recc, dict):    # fused tail: no y_c, no dy_c (sfk_bn_tail_bwd)
-            assert reduced_c is None or reduced_c == "masked"
-            if reduced_c != "masked":                 # the block output's ReLU mask, in place: d_out becomes dz
+            if isinstance(reduced_c, tuple) and reduced_c[0] == "masked+sum":
+                dz_parts = reduced_c[1:]          # the pass that finished d_out masked it and left the partial sums of dz
+            else:
+                assert reduced_c is None
                 esz = 2 if self.dtype == torch.bfloat16 else 4
-                pl.bwd.append(self.be.relu_bits_mask(d_out, bits, d_out), kind="bn_bwd_reduce", layer=f"{tag}.mask",
+                parts = self._buf(f"bparts.{tag}.c", self.max_parts * d_out.c * 2, torch.float32)
+                run, np_ = self.be.bn_bwd_reduce(d_out, None, None, None, None, None, None, True, d_out, parts,
+                                                 self.max_parts, relu_bits=bits)      # mask in place + partial sums
+                pl.bwd.append(run, kind="bn_bwd_reduce", layer=f"{tag}.mask",
                               bytes=float(d_out.pixels * d_out.c * (2 * esz) + d_out.pixels * d_out.c // self.kvec))
-            self._tail_bwd(pl, self._layers[blk.conv_c.conv_key], recc, d_out, dab, tag)
+                dz_parts = (parts, np_)
+            self._tail_bwd(pl, self._layers[blk.conv_c.conv_key], recc, d_out, dab, tag, dz_parts)
             red_b = None
         else:
             # ReLU mask of the block output applied in place (d_out becomes dz, shared by branch2 and the shortcut)
@@ -777,7 +796,9 @@ class Engine:
                 p_tag, p_out, p_recc = prev[1], prev[3], prev[7]
                 fuse = (p_recc, p_out, True, f"{p_tag}.c")
             p_bits = prev[8] if (prev is not None and self.relu_out_mask) else None
-            red_prev = self._dgrad(pl, reca, daa, d_out, accumulate=True, fuse=fuse, out_bits=p_bits)
+            p_tail = prev is not None and isinstance(prev[7], dict)
+            red_prev = self._dgrad(pl, reca, daa, d_out, accumulate=True, fuse=fuse, out_bits=p_bits,
+                                   out_sum_tag=(prev[1] if p_tail else None))
             return d_out, red_prev
         dx = self._fmap(f"dx.{tag}", n, x.t, x.h, x.w, x.c)
         self._dgrad(pl, reca, daa, dx, accumulate=False)
