@@ -41,9 +41,9 @@ for ld in (c4, c4 + 8):
     bits = torch.zeros(pix * C // 8, dtype=torch.uint8, device=dev)
     B = 2.0
     print(f"--- a_b pixel stride {ld} channels ({pix} pixels, {c4} -> {C})")
-    for sums in (False, True):
-        wp = WgradPass(ab, dz, ONE, TAP0, f32(C * c4), 1, c4, C, sum_dy=f32(C) if sums else None)
-        timeit(f"R-wgrad sum_dy={sums}", [be.conv_wgrad(wp)], B * pix * (c4 + C))
+    timeit("R-wgrad (dz^T a_b)", [be.conv_wgrad(WgradPass(ab, dz, ONE, TAP0, f32(C * c4), 1, c4, C))], B * pix * (c4 + C))
+    parts = f32(1024 * C * 2)
+    timeit("mask + sum dz (bn_bwd_reduce, y = NULL)", [be.bn_bwd_reduce(dz, None, None, None, None, None, None, True, dz, parts, 1024, relu_bits=bits)[0]], B * pix * 2 * C + pix * C / 8)
     if ld > c4:
         wp = WgradPass(full, full, ONE, TAP0, f32(ld * ld), 1, ld, ld)
         need = be.conv_wgrad_workspace_bytes(wp)
@@ -65,4 +65,3 @@ for ld in (c4, c4 + 8):
     m = (torch.randn(c4 * c4, device=dev) * c4 ** -0.5).bfloat16()
     timeit("dgrad pass 1 (dz -> da)", [be.conv_igemm(ConvPass(dz, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, wd, 1, C, c4))], B * pix * (c4 + C))
     timeit("dgrad pass 2 (a_b -> da +=, bias)", [be.conv_igemm(ConvPass(ab, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, m, 1, c4, c4, accumulate=True, ep=ConvEpilogue(shift=torch.zeros(c4, device=dev))))], B * pix * 3 * c4)
-    timeit("relu_bits_mask (in place)", [be.relu_bits_mask(dz, bits, dz)], B * pix * 2 * C + pix * C / 8)
