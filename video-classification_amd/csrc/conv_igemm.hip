@@ -277,9 +277,34 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
 // accumulators -- the conv output of a bottleneck's conv_c never reaches HBM; also the "+ bias" of the second
 // data-gradient pass of that tail.  Rows are the output pixels (lin_out).  All loads of a fragment row group (old values,
 // shortcut) are issued before the first store (a load behind a store waits out a round trip: see load8_old).
+// shortcut rows of one tile, fetched BEFORE the K loop by the kernels that can afford the registers (a conv_c has 2..4
+// K-steps: with the shortcut read only in the epilogue a tile's life is DMA round trip + shortcut round trip + stores,
+// strictly one after the other -- 279 us for a layer whose bytes take 190 us)
+template <int FM, int FN> struct ResPre { bf16x8 v[FM][(FN + 1) / 2]; };
+
 template <typename T, int FM, int FN, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void prefetch_res(const ConvK& k, ResPre<FM, FN>& pre, int mt, int nt, int wm, int wn, int lane) {
+  if constexpr (sizeof(T) == 2 && (FN % 2) == 0) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int co_w = nt * BN + wn * (BN / WN);
+    const __amdgpu_buffer_rsrc_t r_res = sfk_make_rsrc(k.ep_res, k.ep_res ? k.ep_rbytes : 0u);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+      const int64_t row = m < k.M ? m : k.M - 1;
+#pragma unroll
+      for (int p = 0; p < FN; p += 2) {
+        const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
+        const int cc = co < k.cout ? co : 0;
+        pre.v[j][p / 2] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_res, (uint32_t)((row * k.ep_rld + k.ep_roff + cc) * 2)));
+      }
+    }
+  }
+}
+
+template <typename T, int FM, int FN, int BM, int BN, int WM, int WN, bool PRE = false>
 __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc)[FN][FM], int mt, int nt, int wm, int wn,
-                                               int lane) {
+                                               int lane, const ResPre<FM, FN>* pre = nullptr) {
   const int l15 = lane & 15, g = lane >> 4;
   T* __restrict__ yp = static_cast<T*>(k.y);
   const T* __restrict__ rp = static_cast<const T*>(k.ep_res);
@@ -337,9 +362,13 @@ __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc
         for (int jj = 0; jj < JB; ++jj) {
           const int j = j0 + jj;
           const uint4 o4 = sfk_buffer_load16(r_old, (uint32_t)((rows[j] * k.yld + k.yoff + cc) * 2));
-          const uint4 r4 = sfk_buffer_load16(r_res, (uint32_t)((rows[j] * k.ep_rld + k.ep_roff + cc) * 2));
           oldv[jj] = __builtin_bit_cast(bf16x8, o4);
-          resv[jj] = __builtin_bit_cast(bf16x8, r4);
+          if constexpr (PRE) {
+            resv[jj] = pre->v[j][p / 2];
+          } else {
+            const uint4 r4 = sfk_buffer_load16(r_res, (uint32_t)((rows[j] * k.ep_rld + k.ep_roff + cc) * 2));
+            resv[jj] = __builtin_bit_cast(bf16x8, r4);
+          }
         }
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj) {
@@ -922,6 +951,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
   for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ResPre<(EPI == 4 ? FM : 1), (EPI == 4 ? FN : 2)> respre;
+  if constexpr (EPI == 4) prefetch_res<T, FM, FN, BM, BN, WM, WN>(k, respre, mt, nt, wm, wn, lane);
 
   // fragment addresses inside a ring slot are loop-invariant; the slot base is a compile-time constant (ring unrolled)
   int a_off[FN], b_off[FM];
@@ -979,6 +1010,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_ige
     epilogue_fused<T, FM, FN, BM, BN, WM, WN>(k, acc, mt, nt, wm, wn, lane);
     return;
   }
+  if constexpr (EPI == 4) {
+    epilogue_fused<T, FM, FN, BM, BN, WM, WN, true>(k, acc, mt, nt, wm, wn, lane, &respre);
+    return;
+  }
   epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, false>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
 }
 
@@ -995,7 +1030,8 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
     if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || wbytes >= 0x7FF00000ll) return {128, 128, false};
     // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
     // once the grid still fills the chip
-    if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k) return {256, 128, true};
+    // a shortcut in the fused epilogue is pre-fetched before the K loop: that needs the 4-wave tile's register budget
+    if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr) return {256, 128, true};
     return {128, 128, true};
   }
   if (cout > 64) return {128, 128, false};
@@ -1099,6 +1135,7 @@ int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
   }
   if (k.ep_on) {
     if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 3>), grid, dim3(512), 0, s, k);
+    else if (k.ep_res) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
