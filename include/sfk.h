@@ -405,7 +405,7 @@ typedef struct {
   int32_t nt_apply_mb;        /* 0:    non-temporal loads+stores in sfk_bn_apply for maps >= this many MB (-1 off) */
   int32_t nt_reduce_mb;       /* 48:   non-temporal loads in sfk_bn_bwd_reduce                                    */
   int32_t nt_bwd_apply_mb;    /* 150:  non-temporal loads+stores in sfk_bn_bwd_apply                              */
-  int32_t reserved;
+  int32_t igemm_pw_stream;    /* 1:    streaming kernel for small-filter pointwise convs with a fused shortcut / ReLU     */
   int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
 } sfk_tuning;
 void sfk_default_tuning(sfk_tuning* out);

@@ -1191,6 +1191,15 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x);
   k.wbytes = (uint32_t)((int64_t)d->cout * d->wtaps * d->cin * (d->x.dtype == SFK_BF16 ? 2 : 4));
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
+  if constexpr (sizeof(T) == 2) {
+    // the block tail's conv_c (small filter, shortcut / ReLU in the epilogue): the streaming kernel of conv_pw.hip
+    if (k.ep_on && (d->ep.res.ptr || d->ep.relu) && !d->accumulate && sfk_tune().igemm_pw_stream && d->ntaps == 1 &&
+        d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 && d->gs[2] == 1 &&
+        k.lin_out && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w) {
+      const int r = sfk_conv_pw_fused(d, s);
+      if (r != SFK_ERR_UNSUPPORTED) return r;
+    }
+  }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;

@@ -1,0 +1,210 @@
+// Streaming pointwise convolution with the fused output transform (sfk_conv_epilogue), bf16:
+//     Y[pix][co] = ReLU( scale[co] * sum_k X[pix][k] W[co][k] + shift[co] + res[pix][co] * rs[co] + rh[co] )   (+ ReLU bitmap)
+// for the conv_c -> norm_c -> + shortcut -> ReLU tail of a bottleneck block with a SMALL filter (cout * K * 2 B <= 128 KB).
+//
+// Why not the implicit-GEMM kernel: with K = 8..128 a 128-pixel tile is 1..4 K-steps of work; one tile per workgroup makes
+// the tile's life  DMA round trip -> (shortcut round trip) -> stores  with nothing to overlap them but the other resident
+// workgroup (measured 262 us for 0.95 GB, the rate of the plain output-heavy conv).  Here nothing is tiled over workgroups:
+//   * the whole filter sits in LDS (loaded once per workgroup, the swizzled [row][32 k] slabs of conv_igemm's Tile<bf16>);
+//   * a WAVE owns 16-pixel rows of the output and walks the map with a stride of all waves; the MFMA B operand (pixels) is
+//     read straight from HBM in fragment layout -- lane (pixel l15, k group g) loads its 16 bytes, no LDS staging, no barrier;
+//   * software pipeline one tile deep: the loads of tile i+1 (X and the shortcut rows, up to 12 x 16 B per lane) are in
+//     flight while tile i runs its MFMAs and its epilogue; 8 waves per CU keep ~80 KB in flight;
+//   * epilogue as conv_igemm's: v_permlane16_swap pairs -> 8 consecutive channels per lane -> 16-byte stores.
+#include "sfk_common.h"
+
+namespace {
+
+struct PwK {
+  const void* x;
+  void* y;
+  const void* w;
+  const void* res;
+  const float *scale, *shift, *rscale, *rshift;
+  uint8_t* bits;
+  int xld, xoff, yld, yoff, rld, roff;
+  int M, K, cout, relu;
+  uint32_t xbytes, ybytes, rbytes;
+};
+
+// 16-byte slot g of row r of a [rows][32 k] bf16 slab (as Tile<bf16>::off in conv_igemm.hip)
+__device__ __forceinline__ int slab_off(int r, int s) { return r * 64 + ((s ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); }
+
+__device__ __forceinline__ void swap16f(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+// NF: co fragments (16 channels) per wave; KS: 32-wide K steps; CG: co groups (waves of a group share a co range)
+template <int NF, int KS, int CG>
+__global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
+  constexpr int CW = NF * 16;                 // channels per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;                            // KS slabs of [cout][32]
+  float* coef = reinterpret_cast<float*>(smem + KS * k.cout * 64);   // scale | shift(+rshift) | rscale, cout floats each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  // ---- filter -> LDS: 16-byte segments, zero beyond K
+  {
+    const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, (uint32_t)k.cout * (uint32_t)k.K * 2u);
+    const int segs = k.cout * KS * 4;
+    for (int i = tid; i < segs; i += 256) {
+      const int s = i & 3, ks = (i >> 2) % KS, r = i / (4 * KS);
+      const int kk = ks * 32 + s * 8;
+      const uint4 v = sfk_buffer_load16(wrs, kk < k.K ? (uint32_t)((r * k.K + kk) * 2) : SFK_OOB);
+      *reinterpret_cast<uint4*>(wl + ks * k.cout * 64 + slab_off(r, s)) = v;
+    }
+    for (int i = tid; i < k.cout; i += 256) {
+      coef[i] = k.scale ? k.scale[i] : 1.f;
+      coef[k.cout + i] = (k.shift ? k.shift[i] : 0.f) + ((k.res && k.rshift) ? k.rshift[i] : 0.f);
+      coef[2 * k.cout + i] = (k.res && k.rscale) ? k.rscale[i] : 1.f;
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
+  const __amdgpu_buffer_rsrc_t rrs = sfk_make_rsrc(k.res, k.res ? k.rbytes : 0u);
+  const bool has_res = k.res != nullptr;
+  // waves of one co group walk the 16-pixel tiles with a stride of (all waves) / CG
+  const int wg = (blockIdx.x * 4 + wave);
+  const int cgi = wg % CG, wi = wg / CG, nw = (gridDim.x * 4) / CG;
+  const int co_w = cgi * CW;
+  const int ntiles = (k.M + 15) >> 4;
+  const bf16_t* __restrict__ dummy = nullptr;
+  (void)dummy;
+
+  uint4 xc[KS], xn[KS];
+  uint4 rc[NF / 2], rn[NF / 2];
+  auto issue = [&](int tile, uint4 (&xv)[KS], uint4 (&rv)[NF / 2]) __attribute__((always_inline)) {
+    int m = tile * 16 + l15;
+    if (m >= k.M) m = k.M - 1;                                   // ragged last tile: re-read the last row (not stored)
+    const uint32_t xrow = (uint32_t)(((int64_t)m * k.xld + k.xoff) * 2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = ks * 32 + g * 8;
+      xv[ks] = sfk_buffer_load16(xrs, kk < k.K ? xrow + (uint32_t)(kk * 2) : SFK_OOB);
+    }
+    if (has_res) {
+      const uint32_t rrow = (uint32_t)(((int64_t)m * k.rld + k.roff + co_w) * 2);
+#pragma unroll
+      for (int p = 0; p < NF / 2; ++p)
+        rv[p] = sfk_buffer_load16(rrs, rrow + (uint32_t)((32 * p + 16 * (g & 1) + 8 * (g >> 1)) * 2));
+    }
+  };
+
+  int tile = wi;
+  if (tile >= ntiles) return;
+  issue(tile, xc, rc);
+  bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
+  for (; tile < ntiles; tile += nw) {
+    const int nxt = tile + nw;
+    if (nxt < ntiles) issue(nxt, xn, rn);
+    // ---- MFMAs: A = filter fragment (rows = co) from LDS, B = the pixel fragment in registers
+    f32x4 acc[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 b = __builtin_bit_cast(bf16x8, xc[ks]);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + ks * k.cout * 64 + slab_off(co_w + 16 * i + l15, g));
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: fragment pairs -> 8 consecutive channels per lane
+    const int m = tile * 16 + l15;
+    const bool rok = m < k.M;
+    const int64_t yrow = (int64_t)m * k.yld + k.yoff;
+#pragma unroll
+    for (int p = 0; p < NF / 2; ++p) {
+      float v[8] = {acc[2 * p][0], acc[2 * p][1], acc[2 * p][2], acc[2 * p][3],
+                    acc[2 * p + 1][0], acc[2 * p + 1][1], acc[2 * p + 1][2], acc[2 * p + 1][3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) swap16f(v[e], v[4 + e]);
+      const int co = co_w + 32 * p + 16 * (g & 1) + 8 * (g >> 1);
+      const float4 s0 = *reinterpret_cast<const float4*>(coef + co), s1 = *reinterpret_cast<const float4*>(coef + co + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(coef + k.cout + co), h1 = *reinterpret_cast<const float4*>(coef + k.cout + co + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = v[e] * sc[e] + sh[e];
+      if (has_res) {
+        const float4 q0 = *reinterpret_cast<const float4*>(coef + 2 * k.cout + co), q1 = *reinterpret_cast<const float4*>(coef + 2 * k.cout + co + 4);
+        const float rs[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rc[p]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)r8[e] * rs[e];
+      }
+      uint32_t bits = 0;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (k.relu) {
+          bits |= (f[e] > 0.f ? 1u : 0u) << e;
+          f[e] = f[e] > 0.f ? f[e] : 0.f;
+        }
+        o[e] = (bf16_t)f[e];
+      }
+      if (rok) {
+        *reinterpret_cast<bf16x8*>(yp + yrow + co) = o;
+        if (k.bits) k.bits[(int64_t)m * (k.cout >> 3) + (co >> 3)] = (uint8_t)bits;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xc[ks] = xn[ks];
+#pragma unroll
+    for (int p = 0; p < NF / 2; ++p) rc[p] = rn[p];
+  }
+}
+
+template <int NF, int KS, int CG>
+int pw_launch(const PwK& k, hipStream_t s) {
+  const size_t lds = (size_t)KS * k.cout * 64 + (size_t)3 * k.cout * 4;
+  static bool attr_set = false;             // > 64 KB of dynamic LDS needs the opt-in (idempotent, set once per process)
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SFK_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntiles = (k.M + 15) / 16;
+  int blocks = 256 * (lds > 80 * 1024 ? 1 : 2);          // one resident generation: 2 workgroups per CU when LDS allows
+  const int need = (ntiles * CG + 3) / 4;
+  if (blocks > need) blocks = need;
+  blocks = (blocks + CG - 1) / CG * CG;
+  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG>), dim3(blocks), dim3(256), lds, s, k);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+
+}  // namespace
+
+// Called by sfk_conv_igemm's dispatch (conv_igemm.hip) for descriptors it has validated: bf16, one tap at the pixel itself,
+// stride 1, rows = the pixels of y in order, fused output transform with a shortcut or ReLU.  Returns SFK_ERR_UNSUPPORTED
+// for shapes this kernel is not built for (the caller then runs the implicit-GEMM kernel).
+int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
+  const sfk_conv_epilogue& e = d->ep;
+  const int K = d->cin, C = d->cout;
+  if (K > 128 || (K % 8) != 0) return SFK_ERR_UNSUPPORTED;
+  const int KS = (K + 31) / 32;
+  PwK k;
+  k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.res = e.res.ptr;
+  k.scale = e.scale; k.shift = e.shift; k.rscale = e.res_scale; k.rshift = e.res_shift;
+  k.bits = e.relu_bits;
+  k.xld = d->x.ld; k.xoff = d->x.c_off; k.yld = d->y.ld; k.yoff = d->y.c_off;
+  k.rld = e.res.ptr ? e.res.ld : 0; k.roff = e.res.ptr ? e.res.c_off : 0;
+  k.M = (int)sfk_fmap_pixels(&d->y); k.K = K; k.cout = C; k.relu = e.relu;
+  k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
+  k.rbytes = e.res.ptr ? (uint32_t)sfk_fmap_bytes(&e.res) : 0u;
+  if (C == 32 && KS == 1) return pw_launch<2, 1, 1>(k, s);
+  if (C == 64 && KS == 1) return pw_launch<4, 1, 1>(k, s);
+  if (C == 128 && KS == 1) return pw_launch<8, 1, 1>(k, s);
+  // 128 channels per wave (16 fragments spill at 256 VGPRs): wider outputs are split over co groups of waves, each of
+  // which reads the (small) X rows again -- from L1 / L2
+  if (C == 256 && KS == 2) return pw_launch<8, 2, 2>(k, s);
+  if (C == 512 && KS == 4) return pw_launch<8, 4, 4>(k, s);
+  return SFK_ERR_UNSUPPORTED;
+}

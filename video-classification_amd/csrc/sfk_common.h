@@ -7,6 +7,8 @@
 
 // the process-wide tuning table of sfk_init (optim_misc.hip); read-only after the first launch
 __attribute__((visibility("hidden"))) const sfk_tuning& sfk_tune();
+// conv_pw.hip: streaming pointwise conv with the fused output transform (dispatched to by sfk_conv_igemm)
+__attribute__((visibility("hidden"))) int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s);
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
