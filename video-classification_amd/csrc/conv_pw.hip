@@ -36,9 +36,12 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
-// NF: co fragments (16 channels) per wave; KS: 32-wide K steps; CG: co groups (waves of a group share a co range)
-template <int NF, int KS, int CG>
-__global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
+// NF: co fragments (16 channels) per wave; KS: 32-wide K steps; CG: co groups (waves of a group share a co range);
+// NT: threads per workgroup (512 when the filter leaves room for ONE workgroup per CU: still 2 waves per SIMD);
+// XDB: the next tile's X rows have registers of their own (else they are fetched into the current ones once the MFMAs
+// have consumed them: KS = 4 would spill otherwise)
+template <int NF, int KS, int CG, int NT, bool XDB>
+__global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
   constexpr int CW = NF * 16;                 // channels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wl = smem;                            // KS slabs of [cout][32]
@@ -49,13 +52,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
   {
     const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, (uint32_t)k.cout * (uint32_t)k.K * 2u);
     const int segs = k.cout * KS * 4;
-    for (int i = tid; i < segs; i += 256) {
+    for (int i = tid; i < segs; i += NT) {
       const int s = i & 3, ks = (i >> 2) % KS, r = i / (4 * KS);
       const int kk = ks * 32 + s * 8;
       const uint4 v = sfk_buffer_load16(wrs, kk < k.K ? (uint32_t)((r * k.K + kk) * 2) : SFK_OOB);
       *reinterpret_cast<uint4*>(wl + ks * k.cout * 64 + slab_off(r, s)) = v;
     }
-    for (int i = tid; i < k.cout; i += 256) {
+    for (int i = tid; i < k.cout; i += NT) {
       coef[i] = k.scale ? k.scale[i] : 1.f;
       coef[k.cout + i] = (k.shift ? k.shift[i] : 0.f) + ((k.res && k.rshift) ? k.rshift[i] : 0.f);
       coef[2 * k.cout + i] = (k.res && k.rscale) ? k.rscale[i] : 1.f;
@@ -67,16 +70,17 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
   const __amdgpu_buffer_rsrc_t rrs = sfk_make_rsrc(k.res, k.res ? k.rbytes : 0u);
   const bool has_res = k.res != nullptr;
   // waves of one co group walk the 16-pixel tiles with a stride of (all waves) / CG
-  const int wg = (blockIdx.x * 4 + wave);
-  const int cgi = wg % CG, wi = wg / CG, nw = (gridDim.x * 4) / CG;
+  constexpr int WPB = NT / 64;
+  const int wg = (blockIdx.x * WPB + wave);
+  const int cgi = wg % CG, wi = wg / CG, nw = (gridDim.x * WPB) / CG;
   const int co_w = cgi * CW;
   const int ntiles = (k.M + 15) >> 4;
   const bf16_t* __restrict__ dummy = nullptr;
   (void)dummy;
 
-  uint4 xc[KS], xn[KS];
+  uint4 xc[KS], xn[XDB ? KS : 1];
   uint4 rc[NF / 2], rn[NF / 2];
-  auto issue = [&](int tile, uint4 (&xv)[KS], uint4 (&rv)[NF / 2]) __attribute__((always_inline)) {
+  auto issue_x = [&](int tile, uint4 (&xv)[KS]) __attribute__((always_inline)) {
     int m = tile * 16 + l15;
     if (m >= k.M) m = k.M - 1;                                   // ragged last tile: re-read the last row (not stored)
     const uint32_t xrow = (uint32_t)(((int64_t)m * k.xld + k.xoff) * 2);
@@ -85,7 +89,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
       const int kk = ks * 32 + g * 8;
       xv[ks] = sfk_buffer_load16(xrs, kk < k.K ? xrow + (uint32_t)(kk * 2) : SFK_OOB);
     }
+  };
+  auto issue_r = [&](int tile, uint4 (&rv)[NF / 2]) __attribute__((always_inline)) {
     if (has_res) {
+      int m = tile * 16 + l15;
+      if (m >= k.M) m = k.M - 1;
       const uint32_t rrow = (uint32_t)(((int64_t)m * k.rld + k.roff + co_w) * 2);
 #pragma unroll
       for (int p = 0; p < NF / 2; ++p)
@@ -95,11 +103,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
 
   int tile = wi;
   if (tile >= ntiles) return;
-  issue(tile, xc, rc);
+  issue_x(tile, xc);
+  issue_r(tile, rc);
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
   for (; tile < ntiles; tile += nw) {
     const int nxt = tile + nw;
-    if (nxt < ntiles) issue(nxt, xn, rn);
+    if (nxt < ntiles) {
+      if constexpr (XDB) issue_x(nxt, reinterpret_cast<uint4(&)[KS]>(xn));
+      issue_r(nxt, rn);
+    }
     // ---- MFMAs: A = filter fragment (rows = co) from LDS, B = the pixel fragment in registers
     f32x4 acc[NF];
 #pragma unroll
@@ -112,6 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + ks * k.cout * 64 + slab_off(co_w + 16 * i + l15, g));
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
       }
+    }
+    if constexpr (!XDB) {
+      if (nxt < ntiles) issue_x(nxt, xc);      // the MFMAs above have consumed xc
     }
     // ---- epilogue: fragment pairs -> 8 consecutive channels per lane
     const int m = tile * 16 + l15;
@@ -153,29 +168,32 @@ __global__ __launch_bounds__(256, 2) void conv_pw_fused_kernel(const PwK k) {
         if (k.bits) k.bits[(int64_t)m * (k.cout >> 3) + (co >> 3)] = (uint8_t)bits;
       }
     }
+    if constexpr (XDB) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xc[ks] = xn[ks];
+      for (int ks = 0; ks < KS; ++ks) xc[ks] = xn[ks];
+    }
 #pragma unroll
     for (int p = 0; p < NF / 2; ++p) rc[p] = rn[p];
   }
 }
 
-template <int NF, int KS, int CG>
+template <int NF, int KS, int CG, int NT, bool XDB>
 int pw_launch(const PwK& k, hipStream_t s) {
+  constexpr int WPB = NT / 64;
   const size_t lds = (size_t)KS * k.cout * 64 + (size_t)3 * k.cout * 4;
   static bool attr_set = false;             // > 64 KB of dynamic LDS needs the opt-in (idempotent, set once per process)
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG, NT, XDB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SFK_ERR_LAUNCH;
     attr_set = true;
   }
   const int ntiles = (k.M + 15) / 16;
-  int blocks = 256 * (lds > 80 * 1024 ? 1 : 2);          // one resident generation: 2 workgroups per CU when LDS allows
-  const int need = (ntiles * CG + 3) / 4;
+  int blocks = 256 * (NT == 512 ? 1 : 2);               // one resident generation: 8 waves per CU either way
+  const int need = (ntiles * CG + WPB - 1) / WPB;
   if (blocks > need) blocks = need;
-  blocks = (blocks + CG - 1) / CG * CG;
-  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG>), dim3(blocks), dim3(256), lds, s, k);
+  while ((blocks * WPB) % CG) ++blocks;                 // every co group gets the same number of waves
+  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG, NT, XDB>), dim3(blocks), dim3(NT), lds, s, k);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -199,12 +217,14 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   k.M = (int)sfk_fmap_pixels(&d->y); k.K = K; k.cout = C; k.relu = e.relu;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
   k.rbytes = e.res.ptr ? (uint32_t)sfk_fmap_bytes(&e.res) : 0u;
-  if (C == 32 && KS == 1) return pw_launch<2, 1, 1>(k, s);
-  if (C == 64 && KS == 1) return pw_launch<4, 1, 1>(k, s);
-  if (C == 128 && KS == 1) return pw_launch<8, 1, 1>(k, s);
+  if (C == 32 && KS == 1) return pw_launch<2, 1, 1, 256, true>(k, s);
+  if (C == 64 && KS == 1) return pw_launch<4, 1, 1, 256, true>(k, s);
+  if (C == 128 && KS == 1) return pw_launch<8, 1, 1, 256, true>(k, s);
   // 128 channels per wave (16 fragments spill at 256 VGPRs): wider outputs are split over co groups of waves, each of
   // which reads the (small) X rows again -- from L1 / L2
-  if (C == 256 && KS == 2) return pw_launch<8, 2, 2>(k, s);
-  if (C == 512 && KS == 4) return pw_launch<8, 4, 4>(k, s);
+  if (C == 256 && KS == 2) return sfk_tune().igemm_pw_stream == 2 ? pw_launch<4, 2, 4, 256, true>(k, s) : pw_launch<8, 2, 2, 256, true>(k, s);
+  // 134 KB of filter: one 8-wave workgroup per CU; 64 channels per wave (8 fragments at KS = 4 spill), the eight co groups
+  // of a workgroup read the same X rows (L1)
+  if (C == 512 && KS == 4) return pw_launch<4, 4, 8, 512, true>(k, s);
   return SFK_ERR_UNSUPPORTED;
 }
