@@ -7,7 +7,8 @@ import json
 import sys
 
 CLASSES = [  # substring of the kernel name -> bench.py stage name
-    ("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("stem_fwd", "stem_fwd"), ("stem_wgrad", "stem_wgrad"),
+    ("conv_igemm", "conv_igemm"), ("conv_pw_fused", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"),
+    ("bn_tail", "bn_finalize"), ("stem_fwd", "stem_fwd"), ("stem_wgrad", "stem_wgrad"),
     ("bn_bwd_reduce", "bn_bwd_reduce"), ("bn_bwd_apply", "bn_bwd_apply"), ("bn_apply", "bn_apply"),
     ("bn_fold", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"),
     ("maxpool", "pool"), ("head_pool", "pool"), ("adam", "adam"), ("filter_", "filter_refresh"), ("cast_kernel", "filter_refresh"),
