@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BM, int BN, int WM, int WN, int EPI = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 3)) void conv_igemm_dma_kernel(const ConvK k) {
+__global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 3))) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
   constexpr int VEC = 8, SEGS = 4, ROWB = 64;
@@ -1047,6 +1047,12 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
     // wide outputs in bf16: a 256x128 tile (8 waves) needs 25% less L2->LDS traffic per FLOP than 128x128 -- worth it
     // once the grid still fills the chip
     // a shortcut in the fused epilogue is pre-fetched before the K loop: that needs the 4-wave tile's register budget
+    // 256 x 256 (8 waves as 4 x 2, 64 x 128 per wave, ONE workgroup per CU): the pixel tile is fetched once for 256
+    // output channels and a barrier interval carries 32 MFMAs per wave instead of 16 -- for the MFMA-bound layers whose
+    // grid still covers the chip (plain epilogue only: the fused ones sit at their register caps)
+    if ((sfk_tune().igemm_pw_stream & 4) && (cout % 256) == 0 && ktot >= 512 && M >= 256 * 128 && !d->ep.scale && !d->ep.shift &&
+        !d->bnb.partials && !d->out_relu_bits)
+      return {256, 256, true};
     if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr) return {256, 128, true};
     return {128, 128, true};
   }
@@ -1142,7 +1148,12 @@ int validate(const sfk_conv_desc* d) {
   return SFK_OK;
 }
 
-int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s) {
+int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
+  if (bn == 256) {
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, k);
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
   if (k.bn_parts) {
     if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 1>), grid, dim3(512), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
@@ -1221,7 +1232,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
   const dim3 grid((unsigned)(k.mtiles * k.ntiles)), block(256);
   // bf16: LDS-DMA ring for the wide tile; narrow outputs keep the register-staged kernel (higher occupancy, tiny K)
-  if (ts.dma) return launch_dma(k, ts.bm, grid, s);
+  if (ts.dma) return launch_dma(k, ts.bm, grid, s, ts.bn);
   if (k.bn_parts) {          // fused BatchNorm-backward reduce (bf16, cout > 16: tiles of 32..128 output channels)
     if constexpr (sizeof(T) == 2) {
       if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
