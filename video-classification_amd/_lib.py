@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 7        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 8        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -192,7 +192,7 @@ class _Tuning(C.Structure):
                 ("wgrad_target_8w", C.c_int32), ("wgrad_target_4w", C.c_int32), ("wgrad_use_workspace", C.c_int32),
                 ("wgrad_wide_co", C.c_int32), ("bn_parts", C.c_int32), ("nt_apply_mb", C.c_int32),
                 ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("igemm_pw_stream", C.c_int32),
-                ("pool_blocks", C.c_int64)]
+                ("pool_blocks", C.c_int64), ("igemm_tile256", C.c_int32), ("igemm_sg", C.c_int32)]
 
 
 # experiment knobs (tools/gpu_ab_env.sh): read HERE, once, on the host side of the boundary -- the library itself never
@@ -201,7 +201,7 @@ TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK
               "SFK_WGT8": "wgrad_target_8w", "SFK_WGT4": "wgrad_target_4w", "SFK_WGWS_LIB": "wgrad_use_workspace",
               "SFK_WG_WIDECO": "wgrad_wide_co", "SFK_BN_PARTS": "bn_parts", "SFK_NT_APPLY_MB": "nt_apply_mb",
               "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks",
-              "SFK_PW_STREAM": "igemm_pw_stream"}
+              "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_SG": "igemm_sg"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)
@@ -213,6 +213,7 @@ SIGNATURES = {
     "sfk_conv_bnb_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
+    "sfk_conv_igemm_family": [C.POINTER(_ConvDesc)],
     "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
@@ -385,6 +386,10 @@ class HipBackend:
     def conv_epilogue_supported(self, p: ConvPass) -> bool:
         """can this pass run with its fused output transform p.ep (sfk_conv_epilogue_supported)?"""
         return bool(self.lib.sfk_conv_epilogue_supported(C.byref(_c_conv(p))))
+
+    def conv_family(self, p: ConvPass) -> int:
+        """0 register-staged igemm, 1 LDS-DMA igemm, 2 streaming small-filter kernel, 3 streaming pointwise + fused epilogue"""
+        return int(self.lib.sfk_conv_igemm_family(C.byref(_c_conv(p))))
 
     def conv_igemm(self, p: ConvPass):
         d, fn, keep = _c_conv(p), self.lib.sfk_conv_igemm, p

@@ -1050,7 +1050,9 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
     // 256 x 256 (8 waves as 4 x 2, 64 x 128 per wave, ONE workgroup per CU): the pixel tile is fetched once for 256
     // output channels and a barrier interval carries 32 MFMAs per wave instead of 16 -- for the MFMA-bound layers whose
     // grid still covers the chip (plain epilogue only: the fused ones sit at their register caps)
-    if ((sfk_tune().igemm_pw_stream & 4) && (cout % 256) == 0 && ktot >= 512 && M >= 256 * 128 && !d->ep.scale && !d->ep.shift &&
+    // Measured (res4, M = 50,176): 1024 -> 256 (3,1,1) 775 -> 863 TFLOP/s, 256 -> 256 (1,3,3) data gradient 844 -> 882; with
+    // 1024 output channels (784 workgroups, one per CU: 3.06 generations) 810 -> 713 -- so only where ONE tile spans cout.
+    if (sfk_tune().igemm_tile256 && cout == 256 && ktot >= 512 && M >= 256 * 128 && !d->ep.scale && !d->ep.shift &&
         !d->bnb.partials && !d->out_relu_bits)
       return {256, 256, true};
     if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr) return {256, 128, true};
@@ -1227,6 +1229,10 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    const int r = sfk_conv_sg(d, s);         // small filter, large map, plain / += / stats epilogue: the streaming kernel
+    if (r != SFK_ERR_UNSUPPORTED) return r;
+  }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
@@ -1289,6 +1295,19 @@ extern "C" int sfk_conv_relu_out_supported(const sfk_conv_desc* d) {
   c.out_relu_bits = nullptr;
   if (validate(&c) != SFK_OK) return 0;
   return relu_out_ok(d) ? 1 : 0;
+}
+
+extern "C" int sfk_conv_igemm_family(const sfk_conv_desc* d) {
+  if (validate(d) != SFK_OK) return -1;
+  if (d->x.dtype == SFK_BF16) {
+    if (ep_on(d) && (d->ep.res.ptr || d->ep.relu) && !d->accumulate && sfk_tune().igemm_pw_stream && d->ntaps == 1 &&
+        d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 && d->gs[2] == 1 &&
+        lin_out_of(d) && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w && d->cin <= 128 &&
+        ((d->cout == 32 || d->cout == 64 || d->cout == 128) ? d->cin <= 32 : (d->cout == 256 ? (d->cin > 32 && d->cin <= 64) : (d->cout == 512 && d->cin > 96))))
+      return 3;
+    if (sfk_conv_sg_takes(d)) return 2;
+  }
+  return pick_tile(d).dma ? 1 : 0;
 }
 
 extern "C" int sfk_conv_epilogue_supported(const sfk_conv_desc* d) {
