@@ -147,8 +147,8 @@ int sfk_conv_bnb_supported(const sfk_conv_desc* d);  /* 1 if d (ignoring d->bnb)
 int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out_relu_bits) can apply a bitmap, else 0 */
 int sfk_conv_epilogue_supported(const sfk_conv_desc* d); /* 1 if d's ep (as filled in) can run, else 0 */
 /* which kernel family sfk_conv_igemm runs for d (for tests / reports; never changes results beyond fp32 summation order):
- * 0 register-staged implicit GEMM, 1 LDS-DMA implicit GEMM, 2 streaming small-filter kernel (conv_pw.hip: filter resident
- * in LDS, no activation staging), 3 its pointwise variant with the fused output transform; < 0: invalid descriptor */
+ * 0 register-staged implicit GEMM, 1 LDS-DMA implicit GEMM, 3 the streaming pointwise kernel with the fused output transform
+ * (conv_pw.hip: filter resident in LDS, no activation staging); < 0: invalid descriptor */
 int sfk_conv_igemm_family(const sfk_conv_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -412,7 +412,7 @@ typedef struct {
   int32_t igemm_pw_stream;    /* 1:    streaming kernel for small-filter pointwise convs with a fused shortcut / ReLU     */
   int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
   int32_t igemm_tile256;      /* 1:    256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs       */
-  int32_t igemm_sg;           /* 1:    streaming kernel for small-filter convs over large maps (narrow layers)            */
+  int32_t reserved;
 } sfk_tuning;
 void sfk_default_tuning(sfk_tuning* out);
 int sfk_init(const sfk_tuning* t); /* NULL = defaults */

@@ -736,59 +736,3 @@ def test_conv_masked_store_with_dz_sums_bf16(hip):
         assert rel_err(pg.sum(0)[:, 0].cpu(), pc.sum(0)[:, 0]) < 2e-3 and float(pg[:, :, 1].abs().max()) == 0.0
         assert rel_err(pg.sum(0)[:, 0].cpu(), xg.float().cpu().view(-1, cout).sum(0)) < 1e-3     # sums of what was stored
 
-
-SG_CASES = [
-    # cin, cout, kernel, (n, t, h, w), stats, accumulate        (>= 65,536 rows: the streaming small-filter kernel takes them)
-    (8, 8, (1, 3, 3), (2, 8, 64, 64), True, False),             # fast res2 conv_b: 9 taps x 8 channels pack into 3 K-steps
-    (32, 8, (3, 1, 1), (2, 8, 64, 64), True, False),            # fast res2 conv_a
-    (16, 16, (1, 3, 3), (2, 10, 60, 58), True, False),          # ragged rows (69,600: the last 256-pixel block is partial)
-    (64, 64, (1, 3, 3), (1, 4, 128, 128), True, False),         # slow res2 conv_b
-    (256, 64, (1, 1, 1), (1, 4, 128, 128), True, False),        # slow res2 conv_a
-    (64, 256, (1, 1, 1), (1, 4, 128, 128), False, False),       # wide plain output (no statistics)
-    (64, 16, (3, 1, 1), (2, 8, 64, 64), False, True),           # += into dx
-    (8, 32, (1, 1, 1), (2, 8, 64, 66), False, False),
-]
-
-
-@pytest.mark.parametrize("case", SG_CASES, ids=[f"{c[0]}to{c[1]}_k{''.join(map(str, c[2]))}{'_stats' if c[4] else ''}{'_acc' if c[5] else ''}" for c in SG_CASES])
-def test_streaming_small_filter_conv_bf16(hip, case):
-    """conv_pw.hip's conv_sg kernel (sfk_conv_igemm dispatches to it for small filters over large maps) against the CPU
-    restatement, forward and data-gradient passes, BatchNorm partial sums per 256-row block included"""
-    cin, cout, k, (n, t, h, w), stats, acc = case
-    dtype = torch.bfloat16
-    gen = torch.Generator().manual_seed(cin * 7 + cout)
-    emu = EmuBackend()
-    g = ConvGeom(cin, cout, k, (1, 1, 1), (k[0] // 2, k[1] // 2, k[2] // 2))
-    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
-    wt = mk((cout * g.wtaps * cin,), dtype, gen, (g.wtaps * cin) ** -0.5)
-    sp = fwd_pass(g, (t, h, w))
-    outs = []
-    for be, x, dev, st in ((emu, xc, "cpu", 0), (hip, xg, DEV, stream())):
-        gen2 = torch.Generator().manual_seed(3)
-        y = FMap(mk((n * t * h * w * cout,), dtype, gen2).to(dev), n, t, h, w, cout)
-        p = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(dev), g.wtaps, cin, cout, accumulate=acc)
-        mt = be.conv_igemm_mtiles(p)
-        if stats:
-            p.stats = torch.full((mt * cout * 2,), 3.0, device=dev)
-        if be is hip:
-            assert be.conv_family(p) == 2
-        be.conv_igemm(p)(st)
-        outs.append((y.buf, p.stats))
-    torch.cuda.synchronize()
-    (yc, sc), (yg, sg) = outs
-    assert rel_err(yg.float().cpu(), yc.float()) < TOL[dtype]
-    if stats:
-        assert sc.numel() == sg.numel()
-        assert rel_err(sg.cpu().view(-1, cout, 2), sc.view(-1, cout, 2)) < 2e-3      # row by row (256-row blocks)
-    # the data gradient of the same conv through the same kernel (flipped taps, transposed filter)
-    passes, _ = dgrad_passes(g, (t, h, w))
-    wt_t = wt.view(cout, g.wtaps, cin).permute(2, 1, 0).contiguous().reshape(-1)
-    dyc, dyg = fmap_pair(n, cout, t, h, w, dtype, gen)
-    res = []
-    for be, dy, dev, st in ((emu, dyc, "cpu", 0), (hip, dyg, DEV, stream())):
-        dx = FMap(torch.zeros(n * t * h * w * cin, dtype=dtype, device=dev), n, t, h, w, cin)
-        for q in passes:
-            be.conv_igemm(ConvPass(dy, dx, q.rows, q.gs, q.os, q.oo, list(q.taps), wt_t.to(dev), g.wtaps, cout, cin))(st)
-        res.append(dx.buf)
-    torch.cuda.synchronize()
-    assert rel_err(res[1].float().cpu(), res[0].float()) < TOL[dtype]

@@ -1229,10 +1229,6 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
   }
-  if constexpr (sizeof(T) == 2) {
-    const int r = sfk_conv_sg(d, s);         // small filter, large map, plain / += / stats epilogue: the streaming kernel
-    if (r != SFK_ERR_UNSUPPORTED) return r;
-  }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
@@ -1305,7 +1301,6 @@ extern "C" int sfk_conv_igemm_family(const sfk_conv_desc* d) {
         lin_out_of(d) && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w && d->cin <= 128 &&
         ((d->cout == 32 || d->cout == 64 || d->cout == 128) ? d->cin <= 32 : (d->cout == 256 ? (d->cin > 32 && d->cin <= 64) : (d->cout == 512 && d->cin > 96))))
       return 3;
-    if (sfk_conv_sg_takes(d)) return 2;
   }
   return pick_tile(d).dma ? 1 : 0;
 }

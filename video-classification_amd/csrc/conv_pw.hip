@@ -228,285 +228,3 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   if (C == 512 && KS == 4) return pw_launch<4, 4, 8, 512, true>(k, s);
   return SFK_ERR_UNSUPPORTED;
 }
-
-// ------------------------------------------------------------------------------------------------------------------
-// Streaming conv for SMALL filters with taps (the narrow layers: the whole fast pathway, slow res2): the same structure as
-// the pointwise kernel above -- filter resident in LDS, a wave owns 16 output pixels, the MFMA B operand (gathered pixels)
-// straight from memory in fragment layout, no LDS staging of activations, no barrier in the loop -- with the implicit-GEMM
-// kernel's K packing: K is the flattened (tap, channel) axis in 16-byte segments, lane group g of K-step ks fetches segment
-// q = 4 ks + g = (tap, 8-channel group) of its pixel; padding taps and ragged rows read zeros through an out-of-range
-// buffer offset.  Those layers were instruction-bound in the tiled kernels (8..12 VALU per MFMA for staging addresses, LDS
-// writes, barriers); here a K-step costs one address computation and one load per lane.
-// Epilogue: plain store (+= when `accumulate`) and, for cout <= 64, the BatchNorm partial sums.  A wave walks whole
-// 256-pixel blocks (16 tiles; block b -> wave b mod #waves) and leaves ONE partial row per block, stats[b][cout][2] -- the
-// row count and meaning of the tiled kernel's 256-row tiles, so sfk_conv_igemm_mtiles is the same for both kernels.
-namespace {
-
-struct SgK {
-  const void* x;
-  void* y;
-  const void* w;
-  float* stats;
-  int xt, xh, xw, xld, xoff, yld, yoff;
-  int M, cin, cout, ntaps, wtaps, KS, accumulate;
-  int gst, gsh, gsw;
-  FastDiv drw, drh, drt, dspt;
-  uint32_t xbytes, ybytes;
-  sfk_tap taps[SFK_MAX_TAPS];
-};
-
-constexpr int SG_CH = 4;   // K-steps per prefetched chunk
-
-__device__ __forceinline__ float row16_sum_f(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-  return v;
-}
-
-template <int NF, bool STATS>
-__global__ __launch_bounds__(256, 2) void conv_sg_kernel(const SgK k) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWS = NF * 16;                                   // filter rows kept per slab (zero beyond cout)
-  char* wl = smem;                                                // KS slabs of [ROWS][32]
-  int* s_delta = reinterpret_cast<int*>(smem + (size_t)k.KS * ROWS * 64);      // byte offset of each tap inside the map
-  sfk_tap* s_taps = reinterpret_cast<sfk_tap*>(s_delta + SFK_MAX_TAPS);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  {
-    const int Ktot = k.ntaps * k.cin;                             // flattened K of the pass (its taps in table order)
-    const __amdgpu_buffer_rsrc_t wrs = sfk_make_rsrc(k.w, (uint32_t)k.cout * (uint32_t)k.wtaps * (uint32_t)k.cin * 2u);
-    const int segs = ROWS * k.KS * 4;
-    for (int i = tid; i < segs; i += 256) {
-      const int s = i & 3, ks = (i >> 2) % k.KS, r = i / (4 * k.KS);
-      uint32_t tap, cseg;
-      k.dspt.divmod((uint32_t)(ks * 4 + s), tap, cseg);
-      uint32_t off = SFK_OOB;
-      if (r < k.cout && (int)tap < k.ntaps && (int)(ks * 32 + s * 8) < Ktot)
-        off = (uint32_t)(((r * k.wtaps + (int)k.taps[tap].widx) * k.cin + (int)cseg * 8) * 2);
-      *reinterpret_cast<uint4*>(wl + (size_t)ks * ROWS * 64 + slab_off(r, s)) = sfk_buffer_load16(wrs, off);
-    }
-    if (tid < SFK_MAX_TAPS) {
-      const sfk_tap t = k.taps[tid < k.ntaps ? tid : 0];
-      s_taps[tid] = t;
-      s_delta[tid] = (((int)t.dt * k.xh + (int)t.dh) * k.xw + (int)t.dw) * k.xld * 2;
-    }
-  }
-  __syncthreads();
-
-  const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
-  const int wi = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  const int ntiles = (k.M + 15) >> 4;
-  const int nch = (k.KS + SG_CH - 1) / SG_CH;
-
-  struct Pix { int t, h, w; uint32_t base; };
-  auto pix_of = [&](int tile) __attribute__((always_inline)) {
-    Pix p;
-    const int m = tile * 16 + l15;
-    uint32_t q1, rw_, q2, rh_, n_, rt_;
-    k.drw.divmod((uint32_t)m, q1, rw_);
-    k.drh.divmod(q1, q2, rh_);
-    k.drt.divmod(q2, n_, rt_);
-    p.t = (m < k.M && tile < ntiles) ? (int)rt_ * k.gst : -(1 << 28);   // rows past M gather nothing
-    p.h = (int)rh_ * k.gsh;
-    p.w = (int)rw_ * k.gsw;
-    p.base = (uint32_t)((((((int64_t)n_ * k.xt + (int)rt_ * k.gst) * k.xh + p.h) * k.xw + p.w) * k.xld + k.xoff) * 2);
-    return p;
-  };
-  auto issue = [&](const Pix& p, int chunk, uint4 (&xv)[SG_CH]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < SG_CH; ++c) {
-      const int ks = chunk * SG_CH + c;
-      uint32_t tap, cseg;
-      k.dspt.divmod((uint32_t)(ks * 4 + g), tap, cseg);
-      const bool kok = ks < k.KS && (int)tap < k.ntaps;
-      const sfk_tap tp = s_taps[kok ? tap : 0];
-      const int ti = p.t + tp.dt, hi = p.h + tp.dh, wi_ = p.w + tp.dw;
-      const bool ok = kok && (unsigned)ti < (unsigned)k.xt && (unsigned)hi < (unsigned)k.xh && (unsigned)wi_ < (unsigned)k.xw;
-      xv[c] = sfk_buffer_load16(xrs, ok ? p.base + (uint32_t)(s_delta[kok ? tap : 0] + (int)cseg * 16) : SFK_OOB);
-    }
-  };
-
-  float s1[STATS ? NF : 1][4], s2[STATS ? NF : 1][4];
-  if constexpr (STATS) {
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
-  }
-  bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
-  const __amdgpu_buffer_rsrc_t yrs = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
-
-  uint4 xc[SG_CH], xn[SG_CH];
-  const int nblk = (k.M + 255) >> 8;                              // 256-pixel blocks; this wave: wi, wi + nw, ...
-  auto tile_of = [&](int blk, int j) { return blk < nblk ? blk * 16 + j : ntiles; };
-  int blk = wi;
-  Pix pc = pix_of(tile_of(blk, 0)), pn = pc;
-  if (blk < nblk) issue(pc, 0, xc);
-  for (; blk < nblk; blk += nw) {
-    for (int j = 0; j < 16; ++j) {
-      const int tile = blk * 16 + j;
-      f32x4 acc[NF];
-#pragma unroll
-      for (int i = 0; i < NF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ch = 0; ch < nch; ++ch) {
-        // prefetch: the next chunk of this tile, or the first chunk of the wave's next tile (past the end: gathers nothing)
-        if (ch + 1 < nch) {
-          issue(pc, ch + 1, xn);
-        } else {
-          pn = pix_of(j < 15 ? tile + 1 : tile_of(blk + nw, 0));
-          issue(pn, 0, xn);
-        }
-#pragma unroll
-        for (int c = 0; c < SG_CH; ++c) {
-          const int ks = ch * SG_CH + c;
-          if (ks < k.KS) {
-            const bf16x8 b = __builtin_bit_cast(bf16x8, xc[c]);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-              const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + (size_t)ks * ROWS * 64 + slab_off(16 * i + l15, g));
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < SG_CH; ++c) xc[c] = xn[c];
-      }
-      pc = pn;
-      // ---- epilogue of the tile
-      const int m = tile * 16 + l15;
-      const bool rok = m < k.M;
-      const int64_t yrow = (int64_t)(rok ? m : k.M - 1) * k.yld + k.yoff;
-      if constexpr (STATS) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = acc[i][r];                            // rows past M accumulated zeros
-            s1[i][r] += v;
-            s2[i][r] += v * v;
-          }
-      }
-      if constexpr ((NF % 2) == 0) {
-#pragma unroll
-        for (int p = 0; p < NF / 2; ++p) {
-          float v[8] = {acc[2 * p][0], acc[2 * p][1], acc[2 * p][2], acc[2 * p][3],
-                        acc[2 * p + 1][0], acc[2 * p + 1][1], acc[2 * p + 1][2], acc[2 * p + 1][3]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) swap16f(v[e], v[4 + e]);
-          const int co = 32 * p + 16 * (g & 1) + 8 * (g >> 1);
-          const int cc = co < k.cout ? co : 0;
-          if (k.accumulate) {
-            const bf16x8 old = __builtin_bit_cast(bf16x8, sfk_buffer_load16(yrs, (uint32_t)((yrow + cc) * 2)));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-          }
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-          if (rok && co < k.cout) *reinterpret_cast<bf16x8*>(yp + yrow + co) = o;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const int co = 16 * i + 4 * g;
-          const int cc = co < k.cout ? co : 0;
-          float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-          if (k.accumulate) {
-            const bf16x4 old = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(yrs, (int)((yrow + cc) * 2), 0, 0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-          if (rok && co < k.cout) *reinterpret_cast<bf16x4*>(yp + yrow + co) = o;
-        }
-      }
-    }
-    if constexpr (STATS) {      // the block's partial row (fixed summation order: deterministic)
-#pragma unroll
-      for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = row16_sum_f(s1[i][r]), b = row16_sum_f(s2[i][r]);
-          const int co = 16 * i + 4 * g + r;
-          if (l15 == 15 && co < k.cout) {
-            float* o = k.stats + ((int64_t)blk * k.cout + co) * 2;
-            o[0] = a;
-            o[1] = b;
-          }
-          s1[i][r] = 0.f;
-          s2[i][r] = 0.f;
-        }
-    }
-  }
-}
-
-struct SgPlan { bool ok; int nf, ks, blocks; size_t lds; };
-
-SgPlan sg_plan(const sfk_conv_desc* d) {
-  SgPlan p{false, 0, 0, 0, 0};
-  if (!sfk_tune().igemm_sg || d->x.dtype != SFK_BF16) return p;
-  if (d->bnb.partials || d->out_relu_bits || d->ep.scale || d->ep.shift) return p;
-  if (d->os[0] != 1 || d->os[1] != 1 || d->os[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2] || d->rt != d->y.t ||
-      d->rh != d->y.h || d->rw != d->y.w)
-    return p;
-  if ((d->cin % 8) || (d->cout % 4) || d->cout > 256 || (d->stats && d->cout > 64)) return p;
-  if ((d->y.ld % 4) || (d->y.c_off % 4)) return p;
-  const int nf = (d->cout + 15) / 16;
-  if (nf != 1 && nf != 2 && nf != 4 && nf != 8 && nf != 16) return p;
-  if ((nf % 2) == 0 && ((d->cout % 8) || (d->y.ld % 8) || (d->y.c_off % 8))) return p;
-  const int ks = (d->ntaps * (d->cin / 8) + 3) / 4;
-  const size_t lds = (size_t)ks * nf * 16 * 64 + SFK_MAX_TAPS * 8;
-  if (lds > 100 * 1024) return p;
-  // only where the filter is small against the map: every workgroup loads the whole filter once
-  const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
-  if (M < 65536) return p;
-  const int nblk = (int)((M + 255) / 256);
-  int blocks = 256 * (lds > 72 * 1024 ? 1 : 2);
-  if (blocks > (nblk + 3) / 4) blocks = (nblk + 3) / 4;
-  p = SgPlan{true, nf, ks, blocks, lds};
-  return p;
-}
-
-template <int NF>
-int sg_launch(const SgK& k, const SgPlan& p, hipStream_t s) {
-  static bool attr_set[2] = {false, false};
-  const int st = k.stats ? 1 : 0;
-  if (p.lds > 64 * 1024 && !attr_set[st]) {
-    const void* fn = st ? reinterpret_cast<const void*>(&conv_sg_kernel<NF, true>) : reinterpret_cast<const void*>(&conv_sg_kernel<NF, false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 + 512) != hipSuccess) return SFK_ERR_LAUNCH;
-    attr_set[st] = true;
-  }
-  if (k.stats) hipLaunchKernelGGL((conv_sg_kernel<NF, true>), dim3(p.blocks), dim3(256), p.lds, s, k);
-  else hipLaunchKernelGGL((conv_sg_kernel<NF, false>), dim3(p.blocks), dim3(256), p.lds, s, k);
-  SFK_CHECK_LAUNCH();
-  return SFK_OK;
-}
-
-}  // namespace
-
-bool sfk_conv_sg_takes(const sfk_conv_desc* d) { return sg_plan(d).ok; }
-
-int sfk_conv_sg(const sfk_conv_desc* d, hipStream_t s) {
-  const SgPlan p = sg_plan(d);
-  if (!p.ok) return SFK_ERR_UNSUPPORTED;
-  SgK k;
-  k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.stats = d->stats;
-  k.xt = d->x.t; k.xh = d->x.h; k.xw = d->x.w; k.xld = d->x.ld; k.xoff = d->x.c_off; k.yld = d->y.ld; k.yoff = d->y.c_off;
-  k.M = d->x.n * d->rt * d->rh * d->rw; k.cin = d->cin; k.cout = d->cout; k.ntaps = d->ntaps; k.wtaps = d->wtaps; k.KS = p.ks;
-  k.accumulate = d->accumulate;
-  k.gst = d->gs[0]; k.gsh = d->gs[1]; k.gsw = d->gs[2];
-  k.drw.set(d->rw); k.drh.set(d->rh); k.drt.set(d->rt); k.dspt.set(d->cin / 8);
-  k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
-  for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
-  switch (p.nf) {
-    case 1: return sg_launch<1>(k, p, s);
-    case 2: return sg_launch<2>(k, p, s);
-    case 4: return sg_launch<4>(k, p, s);
-    case 8: return sg_launch<8>(k, p, s);
-    default: return sg_launch<16>(k, p, s);
-  }
-}
