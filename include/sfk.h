@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 8
+#define SFK_ABI_VERSION 9
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -273,9 +273,11 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
  *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz)            -> [cout][c]: R;  s = sum dz comes as partial rows from the
  *            kernel that wrote dz (its ReLU-mask pass)
  * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift exactly as sfk_bn_finalize, from `gram`; also
- *   leaves t = W G ([cout][c] fp32) for the backward.  w = the conv's filter [cout][c] in compute precision (w_dtype).
- * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the two data-gradient passes
- *     wd [c][cout] (w_dtype) = (A W)^T      -> pass 1: da  = dz . wd          (sfk_conv_igemm, plain)
+ *   leaves t = W G ([cout][c] fp32) for the backward and, when wd != NULL, the filter of the backward's first
+ *   data-gradient pass  wd [c][cout] (w_dtype) = (A W)^T, A = gamma * invstd  -> pass 1: da = dz . wd (sfk_conv_igemm, plain).
+ *   A needs the forward statistics only, so pass 1 does not wait for R: it runs beside the R filter-gradient call.
+ *   w = the conv's filter [cout][c] in compute precision (w_dtype).
+ * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the second data-gradient pass
  *     ws [cout][c] (w_dtype) = diag(B) W    -> m32 = sfk_conv_wgrad(x = W as a [cout pixels][c] map, dy = ws) = W^T diag(B) W;
  *                                              cast to w_dtype -> pass 2: da += a . m + bias   (accumulate + ep.shift)
  *     bias [c] fp32 = C W
@@ -283,10 +285,10 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
 int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
-                    float* shift, float* t, sfk_stream_t stream);
+                    float* shift, float* t, void* wd, sfk_stream_t stream);
 int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, const float* gram, const float* t,
                     int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma,
-                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* wd, void* ws,
+                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* ws,
                     float* bias, float* coef, sfk_stream_t stream);
 /* r [cout][c]; dz_partials [nparts][cout][2], component 0 = partial sums of dz as the kernel that WROTE dz left them
  * (sfk_bn_bwd_reduce with y == NULL, or the data-gradient pass with bnb.y_bn.ptr == NULL + out_relu_bits); coef: [cout][4]

@@ -141,7 +141,7 @@ class EmuBackend:
         return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
 
     # ------------------------------------------------------------------ bottleneck tail (sfk_bn_tail_*, sfk_relu_bits_mask)
-    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, t):
+    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, t, wd=None):
         def run(stream):
             Gx = gram[: gld * gld].view(gld, gld).double()
             G, g, n = Gx[:c, :c], Gx[c, :c], float(Gx[c, c])
@@ -156,6 +156,8 @@ class EmuBackend:
             sc = gamma[:cout].double() * is_
             scale[:cout].copy_(sc.float())
             shift[:cout].copy_((beta[:cout].double() - mu * sc).float())
+            if wd is not None:
+                wd[: cout * c].copy_((sc[:, None] * W).t().contiguous().reshape(-1).to(wd.dtype))
             if rm is not None:
                 unb = var * n / (n - 1.0) if n > 1 else var
                 rm[:cout].mul_(1 - momentum).add_(momentum * mu.float())
@@ -164,7 +166,7 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws,
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws,
                     bias, coef):
         def run(stream):
             R = r[: cout * c].view(cout, c).double()
@@ -182,7 +184,6 @@ class EmuBackend:
             B = -A * c2 * is_
             Cc = A * (c2 * is_ * mu - c1)
             dw[: cout * c].add_((A[:, None] * R + B[:, None] * T + Cc[:, None] * g[None, :]).float().reshape(-1))
-            wd[: cout * c].copy_((A[:, None] * W).t().contiguous().reshape(-1).to(wd.dtype))
             ws[: cout * c].copy_((B[:, None] * W).reshape(-1).to(ws.dtype))
             bias[:c].copy_((Cc @ W).float())
         return run

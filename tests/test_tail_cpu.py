@@ -55,7 +55,8 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     be.conv_wgrad(WgradPass(full, full, ONE, TAP0, gram, 1, gld, gld))(stream)
     mean, invstd, scale, shift, T = f32(cout), f32(cout), f32(cout), f32(cout), f32(cout * c)
     rm, rv, nbt = f32(cout), torch.ones(cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
-    be.bn_tail_fwd(gram, c, gld, wq, cout, g_, b_, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, T)(stream)
+    wd = torch.zeros(cout * c, dtype=dtype, device=dev)                # (A W)^T: known once the statistics are
+    be.bn_tail_fwd(gram, c, gld, wq, cout, g_, b_, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, T, wd)(stream)
     ep = ConvEpilogue(scale=scale, shift=shift, res=rmap, relu=True, relu_bits=bits)
     if res_affine is not None:
         ep.res_scale, ep.res_shift = res_affine
@@ -70,9 +71,8 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     r = f32(cout * c)
     be.conv_wgrad(WgradPass(av, dz, ONE, TAP0, r, 1, c, cout))(stream)
     dgamma, dbeta, dw, bias, coef = f32(cout), f32(cout), f32(cout * c), f32(c), f32(cout * 4)
-    wd = torch.zeros(cout * c, dtype=dtype, device=dev)
     ws = torch.zeros(cout * c, dtype=dtype, device=dev)
-    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)(stream)
+    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, ws, bias, coef)(stream)
     m32 = f32(c * c)
     wmap = FMap(wq, 1, 1, 1, cout, c)                                  # the filter as a [cout pixels][c] map
     be.conv_wgrad(WgradPass(wmap, FMap(ws, 1, 1, 1, cout, c), ONE, TAP0, m32, 1, c, c))(stream)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 8        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 9        # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -214,8 +214,8 @@ SIGNATURES = {
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_igemm_family": [C.POINTER(_ConvDesc)],
-    "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
-    "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PV, _PF, _PF, _PV],
+    "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV, _PV],
+    "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
@@ -545,18 +545,19 @@ class HipBackend:
 
     # -- the bottleneck tail (conv_c -> norm_c without the conv output in HBM)
     def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
-                    scale, shift, t):
-        ts = (gram, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t)
+                    scale, shift, t, wd=None):
+        """wd: optional [c][cout] filter (A W)^T of the backward's first data-gradient pass (include/sfk.h)"""
+        ts = (gram, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t, wd)
         return self._plain("sfk_bn_tail_fwd", _ptr(gram), c, gld, _ptr(w), _DT[w.dtype], cout, _ptr(gamma), _ptr(beta), eps,
                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
-                           _ptr(scale), _ptr(shift), _ptr(t), keep=ts)
+                           _ptr(scale), _ptr(shift), _ptr(t), _ptr(wd), keep=ts)
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws,
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws,
                     bias, coef):
-        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef)
+        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef)
         return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(gram), _ptr(t), c, gld, _ptr(w),
                            _DT[w.dtype], cout, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
-                           _ptr(wd), _ptr(ws), _ptr(bias), _ptr(coef), keep=ts)
+                           _ptr(ws), _ptr(bias), _ptr(coef), keep=ts)
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

@@ -5,9 +5,11 @@
 //     gram [c+V][c+V] fp32 : G = a^T a, row c = column sums g, element (c,c) = pixel count n
 //     r    [cout][c] fp32  : R = dz^T a;  s = sum dz arrives as the partial rows of the kernel that wrote dz
 // What this file computes from them -- everything is O(cout * c^2) or less, i.e. independent of the pixel count:
-//     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift
-//     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the two data-gradient passes
-//               wd = (diag(A) W)^T, ws = diag(B) W (its Gram-like product W^T ws is one more sfk_conv_wgrad call), bias = C W
+//     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift, and
+//               wd = (diag(A) W)^T, A = gamma * invstd: the filter of the backward's FIRST data-gradient pass dz (A W) is
+//               known once the statistics are, so that pass can run beside R = dz^T a instead of behind it
+//     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the second data-gradient pass
+//               ws = diag(B) W (its Gram-like product W^T ws is one more sfk_conv_wgrad call), bias = C W
 // Sums over channels / rows run in double and in a fixed order: deterministic, no atomics.
 #include "sfk_common.h"
 
@@ -26,9 +28,10 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
                                                           int cout, const float* gamma, const float* beta, float eps,
                                                           float momentum, float* running_mean, float* running_var,
                                                           int64_t* nbt, float* mean, float* invstd, float* scale,
-                                                          float* shift, float* __restrict__ t) {
+                                                          float* shift, float* __restrict__ t, D* __restrict__ wd) {
   __shared__ float wl[TF_CO][TF_MAXC];
   __shared__ double red[4 * TF_CO][2];
+  __shared__ float acoef[TF_CO];
   const int co0 = blockIdx.x * TF_CO, tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0 && nbt) nbt[0] += 1;
   for (int i = tid; i < TF_CO * c; i += 256) {
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
   for (int o = 0; o < TF_CO; ++o)
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[o][r] = 0.f;
+#pragma unroll 8                       // 8 rows of G in flight: the loop is bound by the latency of these loads
   for (int j = 0; j < c; ++j) {
     float gj[NR];
 #pragma unroll
@@ -99,12 +103,20 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
     invstd[ch] = is;
     scale[ch] = sc;
     shift[ch] = beta[ch] - (float)mu * sc;
+    acoef[tid] = sc;
     if (running_mean) {
       const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
       running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
       running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
     }
   }
+  if (!wd) return;
+  __syncthreads();
+  // wd[ci][co0 .. co0+7] = A[co] W[co][ci]: TF_CO adjacent output channels per input channel
+  for (int ci = tid; ci < c; ci += 256)
+#pragma unroll
+    for (int o = 0; o < TF_CO; ++o)
+      if (co0 + o < cout) wd[(int64_t)ci * cout + co0 + o] = (D)(acoef[o] * wl[o][ci]);
 }
 
 // one wave per output channel: sum dz*y = W[co] . R[co]; coefficients of dy = A dz + B y + C; dgamma, dbeta
@@ -117,8 +129,10 @@ __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restri
   const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (co >= cout) return;
   double sdy = 0.0;
+#pragma unroll 4
   for (int ci = lane; ci < c; ci += 64) sdy += (double)wload<D>(w, (int64_t)co * c + ci) * (double)rx[(int64_t)co * c + ci];
   double s = 0.0;                                          // sum dz: the partial rows [nparts][cout][2], component 0
+#pragma unroll 8
   for (int p = lane; p < nparts; p += 64) s += (double)parts[((int64_t)p * cout + co) * 2];
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) {
@@ -138,34 +152,22 @@ __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restri
   coef[co * 4 + 3] = 0.f;
 }
 
-// 32 x 32 (co, ci) tiles: dW += A R + B T + C g;  ws = B W;  wd = (A W)^T through LDS (coalesced both ways)
+// 32 x 32 (co, ci) tiles: dW += A R + B T + C g;  ws = B W
 template <typename D>
 __global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restrict__ rx, const float* __restrict__ gram,
                                                             const float* __restrict__ t, int c, int gld, const void* w,
-                                                            int cout, const float* __restrict__ coef, float* dw, D* wd,
-                                                            D* ws) {
-  __shared__ float tile[32][33];
+                                                            int cout, const float* __restrict__ coef, float* dw, D* ws) {
   const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int co = co0 + ty + 8 * i, ci = ci0 + tx;
-    float aw = 0.f;
     if (co < cout && ci < c) {
       const float A = coef[co * 4], B = coef[co * 4 + 1], Cc = coef[co * 4 + 2];
       const int64_t idx = (int64_t)co * c + ci;
-      const float wv = wload<D>(w, idx);
       dw[idx] += A * rx[idx] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
-      ws[idx] = (D)(B * wv);
-      aw = A * wv;
+      ws[idx] = (D)(B * wload<D>(w, idx));
     }
-    tile[ty + 8 * i][tx] = aw;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ci = ci0 + ty + 8 * i, co = co0 + tx;
-    if (co < cout && ci < c) wd[(int64_t)ci * cout + co] = (D)tile[tx][ty + 8 * i];
   }
 }
 
@@ -200,7 +202,7 @@ inline bool tail_args_ok(int c, int gld, int cout, int dtype) {
 extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale, float* shift,
-                               float* t, sfk_stream_t stream) {
+                               float* t, void* wd, sfk_stream_t stream) {
   if (!gram || !w || !gamma || !beta || !mean || !invstd || !scale || !shift || !t) return SFK_ERR_INVALID;
   if (!tail_args_ok(c, gld, cout, w_dtype) || (!running_mean) != (!running_var)) return SFK_ERR_INVALID;
   if (c > TF_MAXC) return SFK_ERR_UNSUPPORTED;
@@ -208,10 +210,10 @@ extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const 
   const dim3 grid((cout + TF_CO - 1) / TF_CO), blk(256);
   if (w_dtype == SFK_BF16)
     hipLaunchKernelGGL(bn_tail_fwd_kernel<bf16_t>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
-                       running_mean, running_var, nbt, mean, invstd, scale, shift, t);
+                       running_mean, running_var, nbt, mean, invstd, scale, shift, t, static_cast<bf16_t*>(wd));
   else
     hipLaunchKernelGGL(bn_tail_fwd_kernel<float>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
-                       running_mean, running_var, nbt, mean, invstd, scale, shift, t);
+                       running_mean, running_var, nbt, mean, invstd, scale, shift, t, static_cast<float*>(wd));
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -219,11 +221,11 @@ extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const 
 template <typename D>
 static int tail_bwd_launch(const float* rx, const float* parts, int nparts, const float* gram, const float* t, int c, int gld, const void* w, int cout,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                           float* dw, void* wd, void* ws, float* bias, float* coef, hipStream_t s) {
+                           float* dw, void* ws, float* bias, float* coef, hipStream_t s) {
   hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, parts, nparts, gram, c, gld, w, cout, gamma, mean,
                      invstd, dgamma, dbeta, coef);
   hipLaunchKernelGGL(bn_tail_apply_kernel<D>, dim3((c + 31) / 32, (cout + 31) / 32), dim3(256), 0, s, rx, gram, t, c, gld,
-                     w, cout, coef, dw, static_cast<D*>(wd), static_cast<D*>(ws));
+                     w, cout, coef, dw, static_cast<D*>(ws));
   hipLaunchKernelGGL(bn_tail_bias_kernel<D>, dim3((c + 15) / 16), dim3(256), 0, s, w, c, cout, coef, bias);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
@@ -231,13 +233,13 @@ static int tail_bwd_launch(const float* rx, const float* parts, int nparts, cons
 
 extern "C" int sfk_bn_tail_bwd(const float* rx, const float* parts, int32_t nparts, const float* gram, const float* t,
                                int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
-                               float* dgamma, float* dbeta, float* dw, void* wd, void* ws, float* bias, float* coef,
+                               float* dgamma, float* dbeta, float* dw, void* ws, float* bias, float* coef,
                                sfk_stream_t stream) {
-  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !wd || !ws || !bias || !coef)
+  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !ws || !bias || !coef)
     return SFK_ERR_INVALID;
   if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return w_dtype == SFK_BF16
-             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s)
-             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, wd, ws, bias, coef, s);
+             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef, s)
+             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef, s);
 }

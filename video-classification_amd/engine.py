@@ -158,6 +158,7 @@ class Engine:
         # upper bound: the tail's fixed cost is O(cout * c^2) (T = W G, W^T B W) whatever the map size, what it saves is
         # O(pixels * cout) -- it pays on the large maps of the early stages (c <= 128), not on res4 / res5 (c = 256 / 512)
         self.tail_max_c = int(os.environ.get("SFK_TAIL_MAXC", "128"))
+        self.tail_r_lane = os.environ.get("SFK_TAIL_RLANE", "0") == "1"    # R = dz^T a beside the first dgrad pass (_tail_bwd)
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -642,9 +643,10 @@ class Engine:
             mean = self._buf(f"mean.{tag}.c", C, torch.float32)
             invstd = self._buf(f"invstd.{tag}.c", C, torch.float32)
             t = self._buf(f"tailT.{tag}", C * c4, torch.float32)
+            wd = self._buf(f"tailWd.{tag}", C * c4)       # (A W)^T, A = gamma * invstd: the backward's first dgrad filter
             pl.fwd.append(self.be.bn_tail_fwd(gram, c4, gld, w, C, gamma, beta, self.spec.bn_eps, self.spec.bn_momentum,
-                                              Lc.rm, Lc.rv, Lc.nbt, mean, invstd, scale, shift, t))
-            tail = dict(full=full, ab=ab, gram=gram, t=t, mean=mean, invstd=invstd, gld=gld)
+                                              Lc.rm, Lc.rv, Lc.nbt, mean, invstd, scale, shift, t, wd))
+            tail = dict(full=full, ab=ab, gram=gram, t=t, mean=mean, invstd=invstd, gld=gld, wd=wd)
         else:
             pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, Lc.rm, Lc.rv, self.spec.bn_eps, C, scale, shift))
         bits = self._buf(f"relubits.{tag}", out.pixels * (C // V), torch.uint8) if train else None
@@ -689,17 +691,32 @@ class Engine:
         wp = WgradPass(ab, d_out, (1, 1, 1), self.TAP0, r, 1, c4, C)
         meta = dict(kind="conv_wgrad", layer=Lc.cb.conv_key, cout=C, flops=2.0 * d_out.pixels * C * c4,
                     bytes=float(esz * (ab.pixels * c4 + d_out.pixels * C) + 4 * C * c4))
+        # R = dz^T a_b may run BESIDE the first data-gradient pass dz (A W), whose filter the forward left (A = gamma * invstd
+        # needs no gradient statistics): tail_r_lane puts it on the pathway's filter-gradient lane and the pathway waits for
+        # it only before the small algebra that needs it.  Measured: see DESIGN.md section 4b (the lane carries a backlog of
+        # earlier filter gradients; lanes of its own exceed the 4 hardware queues a process gets and serialise).
+        home = pl.bwd.cur_lane
+        rl = home + 2 if (self.wgrad_lanes and self.tail_r_lane) else home
+        if rl != home:
+            pl.bwd.sync(rl, home)
+            pl.bwd.cur_lane = rl
         if self.deterministic_wgrad:
-            self._ws_wgrad(pl.bwd, wp, f"b{pl.bwd.cur_lane}", **meta)
+            self._ws_wgrad(pl.bwd, wp, f"b{rl}", **meta)
         else:
             pl.bwd.append(self.be.conv_wgrad(wp), **meta)
-        wd = self._buf(f"tailWd.{tag}", C * c4)
+        pl.bwd.cur_lane = home
+        rows = (d_out.t, d_out.h, d_out.w)
+        pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, tail["wd"], 1, C, c4)),
+                      kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
+                      bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
+        if rl != home:
+            pl.bwd.sync(home, rl)
         ws = self._buf(f"tailWs.{tag}", C * c4)
         bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
         coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
         pl.bwd.append(self.be.bn_tail_bwd(r, dz_parts[0], dz_parts[1], tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
                                           tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
-                                          self._gslice(Lc.w_off, Lc.w_numel), wd, ws, bias, coef))
+                                          self._gslice(Lc.w_off, Lc.w_numel), ws, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
         pl.grad_marks.append((len(pl.bwd), (Lc.w_off, round_up(Lc.w_numel, self.vec))))
         # m = W^T diag(B) W: one more filter-gradient call, its "pixels" are conv_c's output channels
@@ -711,10 +728,6 @@ class Engine:
         else:
             m = self._buf(f"tailM.{tag}", c4 * c4)
             pl.bwd.append(self.be.cast(m32, m, c4 * c4))
-        rows = (d_out.t, d_out.h, d_out.w)
-        pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, wd, 1, C, c4)),
-                      kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
-                      bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
         pl.bwd.append(self.be.conv_igemm(ConvPass(ab, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, m, 1, c4, c4,
                                                   accumulate=True, ep=ConvEpilogue(shift=bias))),
                       kind="conv_dgrad", layer=Lc.cb.conv_key + ":m", cout=c4, flops=2.0 * d_out.pixels * c4 * c4,
@@ -1015,7 +1028,9 @@ class Engine:
             op(stream)
 
     _plan_serial = 0
-    NLANES = 4     # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway
+    # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway.  Not more: a process gets
+    # 4 hardware queues (GPU_MAX_HW_QUEUES), streams beyond that share one and serialise (6 lanes: 948 vs 1033 clips/s)
+    NLANES = 4
 
     def lane_streams(self):
         """torch streams the schedule's lanes run on (one entry when the schedule is single-stream / on the CPU)"""
