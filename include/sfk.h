@@ -302,6 +302,24 @@ int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* argmax, int32
 int sfk_maxpool_bwd(const sfk_fmap* dy, const uint8_t* argmax, const sfk_fmap* dx, int32_t k, int32_t s,
                     int32_t p, sfk_stream_t stream);
 
+/* The stem's  BatchNorm3d -> ReLU -> MaxPool3d  (my_slowfast.py:63-68) without the activation map in HBM.
+ * sfk_bn_maxpool_fwd:  out = maxpool(relu(y * scale + shift) rounded to the map's dtype), argmax as sfk_maxpool_fwd --
+ *   bit-identical to sfk_bn_apply(relu) followed by sfk_maxpool_fwd.
+ * The backward never stores the gradient of the activation either: with da = sfk_maxpool_bwd(d_out, argmax) rebuilt on
+ * the fly and dz = da * [y * scale + shift > 0],
+ *   sfk_bn_maxpool_bwd_reduce: partials[nparts][c][2] = partial (sum dz, sum dz * x_hat)   (-> sfk_bn_bwd_finalize)
+ *   sfk_bn_maxpool_bwd_apply : dy = coef0 * (dz - coef1 - x_hat * coef2)                  (coef of sfk_bn_bwd_finalize)
+ * -- the results of sfk_maxpool_bwd + sfk_bn_bwd_reduce + sfk_bn_bwd_apply.  Backward: window (3, 2, 1) only
+ * (d_out extents = pooled extents of y), SFK_ERR_INVALID otherwise. */
+int sfk_bn_maxpool_fwd(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* out, uint8_t* argmax,
+                       int32_t k, int32_t s, int32_t p, sfk_stream_t stream);
+int sfk_bn_maxpool_bwd_reduce(const sfk_fmap* d_out, const uint8_t* argmax, const sfk_fmap* y, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* partials,
+                              int32_t max_parts, int32_t* nparts_out, sfk_stream_t stream);
+int sfk_bn_maxpool_bwd_apply(const sfk_fmap* d_out, const uint8_t* argmax, const sfk_fmap* y, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, const float* coef,
+                             const sfk_fmap* dy, sfk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Head: AvgPool3d(kernel, stride 1) per pathway -> concat -> Dropout(p) -> Linear at every position ->
  * global mean (my_slowfast.py:75; pytorchvideo PoolConcatPathway + ResNetBasicHead).  By linearity

@@ -380,6 +380,37 @@ class EmuBackend:
             argmax[: arg.numel()].view_as(arg).copy_(arg)
         return run
 
+    # ---- the stem's BatchNorm -> ReLU -> MaxPool without the activation map: by definition the composition of the
+    # stand-alone calls (include/sfk.h sfk_bn_maxpool_*)
+    @staticmethod
+    def bn_maxpool_supported(k, s, p):
+        return (k, s, p) == (3, 2, 1)
+
+    @staticmethod
+    def _like(m: FMap) -> FMap:
+        return FMap(torch.zeros(m.pixels * m.c, dtype=m.dtype), m.n, m.t, m.h, m.w, m.c)
+
+    def bn_maxpool_fwd(self, y, scale, shift, out, argmax, k, s, p):
+        def run(stream):
+            a = self._like(y)
+            self.bn_apply(y, scale, shift, None, None, None, True, a)(stream)
+            self.maxpool_fwd(a, out, argmax, k, s, p)(stream)
+        return run
+
+    def bn_maxpool_bwd_reduce(self, d_out, argmax, y, mean, invstd, scale, shift, partials, max_parts):
+        def run(stream):
+            da = self._like(y)
+            self.maxpool_bwd(d_out, argmax, da, 3, 2, 1)(stream)
+            self.bn_bwd_reduce(da, y, None, mean, invstd, scale, shift, True, None, partials, max_parts)[0](stream)
+        return run, 1
+
+    def bn_maxpool_bwd_apply(self, d_out, argmax, y, mean, invstd, scale, shift, coef, dy):
+        def run(stream):
+            da = self._like(y)
+            self.maxpool_bwd(d_out, argmax, da, 3, 2, 1)(stream)
+            self.bn_bwd_apply(da, y, None, mean, invstd, scale, shift, True, coef, dy)(stream)
+        return run
+
     def maxpool_bwd(self, dy, argmax, dx, k, s, p):
         def run(stream):
             G = dy.view5().float()

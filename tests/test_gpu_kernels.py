@@ -379,6 +379,62 @@ def test_maxpool_with_ties(hip, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dims", [(2, 16, 3, 12, 14), (3, 8, 2, 7, 9), (1, 64, 2, 16, 16)], ids=str)
+def test_stem_tail_bn_relu_maxpool_fused(hip, dtype, dims):
+    """sfk_bn_maxpool_fwd / _bwd_reduce / _bwd_apply == sfk_bn_apply(relu) -> sfk_maxpool_fwd and sfk_maxpool_bwd ->
+    sfk_bn_bwd_reduce -> sfk_bn_bwd_apply, without the activation map or its gradient: bit-identical pooled values and argmax
+    bytes (ties at the ReLU's zeros included), the same dy."""
+    n, c, t, h, w = dims
+    gen = torch.Generator().manual_seed(sum(dims))
+    emu = EmuBackend()
+    yc, yg = fmap_pair(n, c, t, h, w, dtype, gen)
+    scale, shift = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.3 - 0.8
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    oc, og = fmap_pair(n, c, t, ho, wo, dtype, gen)
+    ac = torch.zeros(oc.pixels * c, dtype=torch.uint8)
+    ag = torch.zeros(oc.pixels * c, dtype=torch.uint8, device=DEV)
+    emu.bn_maxpool_fwd(yc, scale, shift, oc, ac, 3, 2, 1)(0)
+    hip.bn_maxpool_fwd(yg, scale.to(DEV), shift.to(DEV), og, ag, 3, 2, 1)(stream())
+    # the two stand-alone kernels on the same device: the fused pass must reproduce them bit for bit
+    a_g = FMap(torch.zeros(yg.pixels * c, dtype=dtype, device=DEV), n, t, h, w, c)
+    o2 = FMap(torch.zeros(og.pixels * c, dtype=dtype, device=DEV), n, t, ho, wo, c)
+    a2 = torch.zeros_like(ag)
+    hip.bn_apply(yg, scale.to(DEV), shift.to(DEV), None, None, None, True, a_g)(stream())
+    hip.maxpool_fwd(a_g, o2, a2, 3, 2, 1)(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(og.view5(), o2.view5()) and torch.equal(ag, a2)
+    assert rel_err(og.view5().float().cpu(), oc.view5().float()) < TOL[dtype]
+    assert float((ag.cpu() != ac).float().mean()) < 2e-3                   # only where an fma rounding flips a tie
+    ac = ag.cpu()                                                          # the backward below: same routing on both sides
+    assert float((oc.view5().float() == 0).float().mean()) > 0.01          # the case has all-zero windows (ties)
+    # backward
+    v = yc.view5().float().reshape(-1, c)
+    mean, invstd = v.mean(0), 1.0 / torch.sqrt(v.var(0, unbiased=False) + 1e-5)
+    gamma = scale / invstd
+    dc, dg = fmap_pair(n, c, t, ho, wo, dtype, gen)
+    px = yc.pixels
+    res = []
+    for be, dev, y_, d_, a_ in ((emu, "cpu", yc, dc, ac), (hip, DEV, yg, dg, ag)):
+        f = lambda *sh: torch.zeros(*sh, device=dev)
+        to = lambda x: x.to(dev)
+        parts, coef, dgamma, dbeta = f(2048 * c * 2), f(c * 3), f(c), f(c)
+        run, nb = be.bn_maxpool_bwd_reduce(d_, a_, y_, to(mean), to(invstd), to(scale), to(shift), parts, 2048)
+        st = stream() if dev != "cpu" else 0
+        run(st)
+        be.bn_bwd_finalize(parts, nb, c, px, to(gamma), to(invstd), dgamma, dbeta, coef)(st)
+        dy = FMap(torch.zeros(px * c, dtype=dtype, device=dev), n, t, h, w, c)
+        be.bn_maxpool_bwd_apply(d_, a_, y_, to(mean), to(invstd), to(scale), to(shift), coef, dy)(st)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append([x.float().cpu() for x in (dgamma, dbeta, coef, dy.view5())])
+    for a, b in zip(*res):
+        assert rel_err(b, a) < TOL[dtype]
+    # unsupported windows are refused, not mis-computed
+    with pytest.raises(Exception):
+        hip.bn_maxpool_bwd_apply(dg, ag, dg, mean.to(DEV), invstd.to(DEV), scale.to(DEV), shift.to(DEV), coef, dg)(stream())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("geom", [((4, 2, 2), (6, 4, 4)), ((8, 7, 7), (8, 7, 7)), ((1, 1, 1), (2, 2, 2))], ids=["ref", "global", "unit"])
 def test_head_pool_dropout_fc_loss(hip, dtype, geom):
     k, (t, h, w) = geom

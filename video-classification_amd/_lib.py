@@ -232,6 +232,9 @@ SIGNATURES = {
     "sfk_bn_bwd_apply": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _PF, _P_FMAP, _PV],
     "sfk_maxpool_fwd": [_P_FMAP, _P_FMAP, _PV, _I32, _I32, _I32, _PV],
     "sfk_maxpool_bwd": [_P_FMAP, _PV, _P_FMAP, _I32, _I32, _I32, _PV],
+    "sfk_bn_maxpool_fwd": [_P_FMAP, _PF, _PF, _P_FMAP, _PV, _I32, _I32, _I32, _PV],
+    "sfk_bn_maxpool_bwd_reduce": [_P_FMAP, _PV, _P_FMAP, _PF, _PF, _PF, _PF, _PF, _I32, C.POINTER(C.c_int32), _PV],
+    "sfk_bn_maxpool_bwd_apply": [_P_FMAP, _PV, _P_FMAP, _PF, _PF, _PF, _PF, _PF, _P_FMAP, _PV],
     "sfk_head_pool_fwd": [_P_FMAP, _I32, _I32, _I32, _F, _PV, _PF, _I32, _I32, _PV],
     "sfk_head_pool_bwd": [_PF, _I32, _I32, _I32, _I32, _I32, _F, _PV, _P_FMAP, _PV],
     "sfk_head_dropout_mask": [_I32, _I32, _I32, _I32, _F, _PV, _PV, _PV],
@@ -567,6 +570,31 @@ class HipBackend:
     def maxpool_bwd(self, dy: FMap, argmax, dx: FMap, k, s, p):
         fy, fx = _c_fmap(dy), _c_fmap(dx)
         return self._plain("sfk_maxpool_bwd", C.byref(fy), _ptr(argmax), C.byref(fx), k, s, p, keep=(fx, fy, dx, dy, argmax))
+
+    # -- the stem's BatchNorm -> ReLU -> MaxPool without the activation map (include/sfk.h sfk_bn_maxpool_*)
+    @staticmethod
+    def bn_maxpool_supported(k, s, p) -> bool:
+        return (k, s, p) == (3, 2, 1)
+
+    def bn_maxpool_fwd(self, y: FMap, scale, shift, out: FMap, argmax, k, s, p):
+        fy, fo = _c_fmap(y), _c_fmap(out)
+        return self._plain("sfk_bn_maxpool_fwd", C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fo), _ptr(argmax), k, s, p,
+                           keep=(fy, fo, y, out, scale, shift, argmax))
+
+    def bn_maxpool_bwd_reduce(self, d_out: FMap, argmax, y: FMap, mean, invstd, scale, shift, partials, max_parts):
+        """returns (run, nparts)"""
+        fd, fy = _c_fmap(d_out), _c_fmap(y)
+        np_ = C.c_int32(0)
+        run = self._plain("sfk_bn_maxpool_bwd_reduce", C.byref(fd), _ptr(argmax), C.byref(fy), _ptr(mean), _ptr(invstd),
+                          _ptr(scale), _ptr(shift), _ptr(partials), max_parts, C.byref(np_),
+                          keep=(fd, fy, np_, d_out, y, argmax, mean, invstd, scale, shift, partials))
+        return run, self._dry_parts(y, max_parts)
+
+    def bn_maxpool_bwd_apply(self, d_out: FMap, argmax, y: FMap, mean, invstd, scale, shift, coef, dy: FMap):
+        fd, fy, fo = _c_fmap(d_out), _c_fmap(y), _c_fmap(dy)
+        return self._plain("sfk_bn_maxpool_bwd_apply", C.byref(fd), _ptr(argmax), C.byref(fy), _ptr(mean), _ptr(invstd),
+                           _ptr(scale), _ptr(shift), _ptr(coef), C.byref(fo),
+                           keep=(fd, fy, fo, d_out, y, dy, argmax, mean, invstd, scale, shift, coef))
 
     def head_pool_fwd(self, x: FMap, k, rate, seed, feat, feat_ld, f_off):
         fx = _c_fmap(x)

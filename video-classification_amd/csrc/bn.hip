@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
   if (r1 > nparts) r1 = nparts;
   double s1 = 0.0, s2 = 0.0;
   if (ch < c) {
+#pragma unroll 4
     for (int p = r0 + rl; p < r1; p += nrl) {
       const float2 v = *reinterpret_cast<const float2*>(partials + ((int64_t)p * c + ch) * 2);
       s1 += (double)v.x;
@@ -450,6 +451,128 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc,
   }
 }
 
+// ------------------------------------------------------------------ stem tail backward: MaxPool (1,3,3)/(1,2,2)/(0,1,1) + ReLU + BN
+// The gradient of the activation a = relu(bn(y)) under the pool is never stored: both passes rebuild
+//   da[p] = sum over the <= 2 x 2 windows that contain p of [argmax(window) == p] * d_out[window]     (rounded to T, as the
+//   stand-alone sfk_maxpool_bwd would store it), dz = da * [y * scale + shift > 0]
+// from d_out (1/4 of the map) and the argmax bytes; APPLY = false leaves the partial rows (sum dz, sum dz * x_hat),
+// APPLY = true writes dy = c0 * (dz - c1 - x_hat * c2).  Replaces maxpool_bwd + bn_bwd_reduce + bn_bwd_apply:
+// per input element 2 x (y read) + 1 write instead of 4 reads + 3 writes + the da map.
+// A thread owns a 2 x 2 QUAD of input pixels (rows 2a, 2a+1; columns 2b, 2b+1): the quad meets exactly the four windows
+// (a, b), (a, b+1), (a+1, b), (a+1, b+1) -- 4 gradient + 4 argmax loads for 4 pixels (per-pixel gathers would load 16).
+struct PoolGeo {
+  int H, W, Ho, Wo, qh, qw;     // input frame, pooled frame, quads per frame column / row
+  FastDiv dqw, dqh;
+};
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256, APPLY ? 3 : 4) void bn_pool_bwd_kernel(FM dout, const uint8_t* __restrict__ argmax, FM y, FM dyo,
+                                                          int64_t quads, int c, PoolGeo g, const float* mean,
+                                                          const float* invstd, const float* scale, const float* shift,
+                                                          const float* coef, float* partials) {
+  constexpr int VEC = DT<T>::VEC;
+  const int cgs = c / VEC;
+  const ChanMap cm(cgs);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (cm.active) {
+    float mu[VEC], is[VEC], sc[VEC], sh[VEC], c0[VEC], c1[VEC], c2[VEC];
+    load_coef<VEC>(mu, mean, cm.cg);
+    load_coef<VEC>(is, invstd, cm.cg);
+    load_coef<VEC>(sc, scale, cm.cg);
+    load_coef<VEC>(sh, shift, cm.cg);
+    if (APPLY) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        c0[i] = coef[(cm.cg * VEC + i) * 3 + 0];
+        c1[i] = coef[(cm.cg * VEC + i) * 3 + 1];
+        c2[i] = coef[(cm.cg * VEC + i) * 3 + 2];
+      }
+    }
+    const T* gp = static_cast<const T*>(dout.p) + dout.off + cm.cg * VEC;
+    const uint8_t* ap = argmax + cm.cg * VEC;
+    const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
+    T* op = APPLY ? static_cast<T*>(dyo.p) + dyo.off + cm.cg * VEC : nullptr;
+    for (int64_t q = (int64_t)blockIdx.x * cm.rows_b + cm.row; q < quads; q += (int64_t)gridDim.x * cm.rows_b) {
+      uint32_t q1, b, nt, a;
+      g.dqw.divmod((uint32_t)q, q1, b);
+      g.dqh.divmod(q1, nt, a);
+      // windows (a + wa, b + wb), wa, wb in {0, 1}; pixels (2a + ra, 2b + rb)
+      Vec16<T> gw[4], v[4];
+      uint32_t alo[4], ahi[4];
+      bool wok[4], pok[4];
+#pragma unroll
+      for (int wa = 0; wa < 2; ++wa)
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb) {
+          const int ho = (int)a + wa, wo = (int)b + wb, k = 2 * wa + wb;
+          wok[k] = ho < g.Ho && wo < g.Wo;
+          const int hc = ho < g.Ho ? ho : g.Ho - 1, wc = wo < g.Wo ? wo : g.Wo - 1;
+          const int64_t opix = ((int64_t)nt * g.Ho + hc) * g.Wo + wc;
+          gw[k].load(gp + opix * dout.ld);
+          const uint8_t* aq = ap + opix * c;
+          if (VEC == 8) {
+            const uint2 a2 = *reinterpret_cast<const uint2*>(aq);
+            alo[k] = a2.x;
+            ahi[k] = a2.y;
+          } else {
+            alo[k] = *reinterpret_cast<const uint32_t*>(aq);
+            ahi[k] = 0;
+          }
+        }
+      int64_t ipix[4];
+#pragma unroll
+      for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int hi = 2 * (int)a + ra, wi = 2 * (int)b + rb, k = 2 * ra + rb;
+          pok[k] = hi < g.H && wi < g.W;
+          const int hc = hi < g.H ? hi : g.H - 1, wc = wi < g.W ? wi : g.W - 1;
+          ipix[k] = ((int64_t)nt * g.H + hc) * g.W + wc;
+          v[k].load(yp + ipix[k] * y.ld);
+        }
+#pragma unroll
+      for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int k = 2 * ra + rb;
+          if (!pok[k]) continue;
+          Vec16<T> da, o;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            float acc = 0.f;
+            // pixel row 2a + ra lies in window row a + wa at kh = 1 + ra - 2 wa (ra = 0: only wa = 0); same for columns
+#pragma unroll
+            for (int wa = 0; wa <= ra; ++wa)
+#pragma unroll
+              for (int wb = 0; wb <= rb; ++wb) {
+                const int w4 = 2 * wa + wb;
+                const uint32_t code = (uint32_t)((1 + ra - 2 * wa) * 3 + (1 + rb - 2 * wb));
+                const uint32_t am = ((i < 4 ? alo[w4] : ahi[w4]) >> (8 * (i & 3))) & 0xFFu;
+                if (wok[w4] && am == code) acc += gw[w4].get(i);
+              }
+            da.set(i, acc);
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float yv = v[k].get(i);
+            const float dz = (yv * sc[i] + sh[i] > 0.f) ? da.get(i) : 0.f;
+            const float xh = (yv - mu[i]) * is[i];
+            if (APPLY) {
+              o.set(i, c0[i] * (dz - c1[i] - xh * c2[i]));
+            } else {
+              s1[i] += dz;
+              s2[i] += dz * xh;
+            }
+          }
+          if (APPLY) o.store(op + ipix[k] * dyo.ld);
+        }
+    }
+  }
+  if (!APPLY) block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
+}
+
 bool same_shape(const sfk_fmap* a, const sfk_fmap* b) {
   return a->n == b->n && a->t == b->t && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
 }
@@ -646,4 +769,73 @@ extern "C" int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk
   return y->dtype == SFK_BF16
              ? launch_bwd_apply<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s)
              : launch_bwd_apply<float>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s);
+}
+
+// ---- stem tail backward (see bn_pool_bwd_kernel): only the stems' (3, 2, 1) pool
+namespace {
+int bn_pool_check(const sfk_fmap* d_out, const uint8_t* argmax, const sfk_fmap* y, const float* mean, const float* invstd,
+                  const float* scale, const float* shift) {
+  if (!sfk_fmap_ok(d_out) || !sfk_fmap_ok(y) || !argmax || !mean || !invstd || !scale || !shift) return SFK_ERR_INVALID;
+  if (d_out->dtype != y->dtype || d_out->n != y->n || d_out->t != y->t || d_out->c != y->c) return SFK_ERR_INVALID;
+  if (d_out->h != (y->h + 2 - 3) / 2 + 1 || d_out->w != (y->w + 2 - 3) / 2 + 1) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(d_out) || !sfk_fmap_vec_ok(y)) return SFK_ERR_UNSUPPORTED;
+  if (sfk_fmap_pixels(y) >= (1ll << 31)) return SFK_ERR_UNSUPPORTED;
+  return SFK_OK;
+}
+inline PoolGeo pool_geo(const sfk_fmap* d_out, const sfk_fmap* y) {
+  PoolGeo g;
+  g.H = y->h; g.W = y->w; g.Ho = d_out->h; g.Wo = d_out->w;
+  g.qh = (y->h + 1) / 2; g.qw = (y->w + 1) / 2;
+  g.dqw.set(g.qw); g.dqh.set(g.qh);
+  return g;
+}
+inline int64_t pool_quads(const sfk_fmap* y, const PoolGeo& g) { return (int64_t)y->n * y->t * g.qh * g.qw; }
+}  // namespace
+
+extern "C" int sfk_bn_maxpool_bwd_reduce(const sfk_fmap* d_out, const uint8_t* argmax, const sfk_fmap* y, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, float* partials,
+                                         int32_t max_parts, int32_t* nparts_out, sfk_stream_t stream) {
+  const int st = bn_pool_check(d_out, argmax, y, mean, invstd, scale, shift);
+  if (st != SFK_OK) return st;
+  if (!partials || !nparts_out || max_parts <= 0) return SFK_ERR_INVALID;
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  const dim3 grid = chan_grid(y->c / sfk_vec_of(y->dtype), px, max_parts, &np);   // rows as sfk_bn_bwd_reduce would leave
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const PoolGeo g = pool_geo(d_out, y);
+  const int64_t quads = pool_quads(y, g);
+  if (y->dtype == SFK_BF16)
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, fm_of(d_out), argmax, fm_of(y), FM{nullptr, 0, 0},
+                       quads, y->c, g, mean, invstd, scale, shift, nullptr, partials);
+  else
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<float, false>), grid, dim3(256), 0, s, fm_of(d_out), argmax, fm_of(y), FM{nullptr, 0, 0},
+                       quads, y->c, g, mean, invstd, scale, shift, nullptr, partials);
+  SFK_CHECK_LAUNCH();
+  *nparts_out = np;
+  return SFK_OK;
+}
+
+extern "C" int sfk_bn_maxpool_bwd_apply(const sfk_fmap* d_out, const uint8_t* argmax, const sfk_fmap* y, const float* mean,
+                                        const float* invstd, const float* scale, const float* shift, const float* coef,
+                                        const sfk_fmap* dy, sfk_stream_t stream) {
+  const int st = bn_pool_check(d_out, argmax, y, mean, invstd, scale, shift);
+  if (st != SFK_OK) return st;
+  if (!coef || !sfk_fmap_ok(dy) || !same_shape(y, dy)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(dy)) return SFK_ERR_UNSUPPORTED;
+  const int cgs = y->c / sfk_vec_of(y->dtype);
+  const int cgs_b = cgs < 256 ? cgs : 256, rows_b = 256 / cgs_b;
+  const PoolGeo g = pool_geo(d_out, y);
+  const int64_t quads = pool_quads(y, g);
+  int64_t want = (quads + rows_b - 1) / rows_b;                               // one quad per thread
+  if (want > 65535 * 16) want = 65535 * 16;
+  const dim3 grid((unsigned)(want > 0 ? want : 1), (unsigned)((cgs + 255) / 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (y->dtype == SFK_BF16)
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, fm_of(d_out), argmax, fm_of(y), fm_of(dy), quads,
+                       y->c, g, mean, invstd, scale, shift, coef, nullptr);
+  else
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<float, true>), grid, dim3(256), 0, s, fm_of(d_out), argmax, fm_of(y), fm_of(dy), quads,
+                       y->c, g, mean, invstd, scale, shift, coef, nullptr);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
 }

@@ -13,9 +13,13 @@ inline FM fm_of(const sfk_fmap* f) { return FM{f->ptr, f->t, f->h, f->w, f->ld, 
 // ------------------------------------------------------------------ MaxPool (1,k,k)/(1,s,s)/(0,p,p)
 // KC/SC/PC > 0: window / stride / padding known at compile time (the stems' (3, 2, 1)): the window loops unroll and the
 // backward's divisibility tests fold to parity tests
-template <typename T, int KC = 0, int SC = 0, int PC = 0>
+// BN: the input is a raw conv output and the pooled quantity is relu(x * scale + shift) rounded to T -- BatchNorm + ReLU +
+// MaxPool of a stem in one pass (sfk_bn_maxpool_fwd); the activation map itself never exists in HBM
+template <typename T, int KC = 0, int SC = 0, int PC = 0, bool BN = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* argmax, int n, int c, int k_, int s_,
-                                                          int p_, FastDiv dcg, FastDiv dwo, FastDiv dho) {
+                                                          int p_, FastDiv dcg, FastDiv dwo, FastDiv dho,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift) {
   const int k = KC ? KC : k_, s = KC ? SC : s_, p = KC ? PC : p_;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
@@ -27,8 +31,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
     dho.divmod(q1, nt, ho);  // nt = n*T + t (pooling is per frame)
     float best[VEC];
     int arg[VEC];
+    float sc[VEC], sh[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { best[i] = -INFINITY; arg[i] = 0; }
+    for (int i = 0; i < VEC; ++i) {
+      best[i] = -INFINITY;
+      arg[i] = 0;
+      sc[i] = BN ? scale[cg * VEC + i] : 1.f;
+      sh[i] = BN ? shift[cg * VEC + i] : 0.f;
+    }
     bool first = true;
     if (KC) {
       // compile-time window: every tap is loaded (coordinates clamped into the frame, so no branch sits around a load and
@@ -49,9 +59,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
         for (int kw = 0; kw < (KC ? KC : 1); ++kw) {
           const int hi = (int)ho * s - p + kh, wi = (int)wo * s - p + kw;
           const bool in = (unsigned)hi < (unsigned)x.h && (unsigned)wi < (unsigned)x.w;
+          Vec16<T> act;
+          if (BN) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) act.set(i, fmaxf(v[kh * (KC ? KC : 1) + kw].get(i) * sc[i] + sh[i], 0.f));
+          }
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
-            const float f = v[kh * (KC ? KC : 1) + kw].get(i);
+            const float f = BN ? act.get(i) : v[kh * (KC ? KC : 1) + kw].get(i);
             if (in && (first || f > best[i] || f != f)) { best[i] = f; arg[i] = kh * k + kw; }
           }
           first = first && !in;
@@ -65,6 +80,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(FM x, FM y, uint8_t* a
         if ((unsigned)wi >= (unsigned)x.w) continue;
         Vec16<T> v;
         v.load(static_cast<const T*>(x.p) + (((int64_t)nt * x.h + hi) * x.w + wi) * x.ld + x.off + cg * VEC);
+        if (BN) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v.set(i, fmaxf(v.get(i) * sc[i] + sh[i], 0.f));
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const float f = v.get(i);
@@ -434,8 +453,8 @@ inline unsigned grid_for(int64_t total) {
 
 }  // namespace
 
-extern "C" int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* argmax, int32_t k, int32_t s, int32_t p,
-                               sfk_stream_t stream) {
+static int maxpool_fwd_launch(const sfk_fmap* x, const float* scale, const float* shift, const sfk_fmap* y, uint8_t* argmax,
+                              int32_t k, int32_t s, int32_t p, sfk_stream_t stream) {
   if (!sfk_fmap_ok(x) || !sfk_fmap_ok(y) || !argmax || k <= 0 || k > 15 || s <= 0 || p < 0) return SFK_ERR_INVALID;
   if (x->dtype != y->dtype || x->n != y->n || x->t != y->t || x->c != y->c) return SFK_ERR_INVALID;
   if (y->h != (x->h + 2 * p - k) / s + 1 || y->w != (x->w + 2 * p - k) / s + 1) return SFK_ERR_INVALID;
@@ -446,15 +465,31 @@ extern "C" int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* ar
   FastDiv dcg, dwo, dho;
   dcg.set(cgs); dwo.set(y->w); dho.set(y->h);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (x->dtype == SFK_BF16)
-    if (k == 3 && s == 2 && p == 1)
-      hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 3, 2, 1>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
-    else
-      hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
-  else
-    hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho);
+  const dim3 grid(grid_for(total)), blk(256);
+  const bool k321 = k == 3 && s == 2 && p == 1;
+#define SFK_POOL(T, K, S, P, BN) \
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T, K, S, P, BN>), grid, blk, 0, st, fm_of(x), fm_of(y), argmax, x->n, x->c, k, s, p, dcg, dwo, dho, scale, shift)
+  if (scale) {
+    if (x->dtype == SFK_BF16) { if (k321) SFK_POOL(bf16_t, 3, 2, 1, true); else SFK_POOL(bf16_t, 0, 0, 0, true); }
+    else SFK_POOL(float, 0, 0, 0, true);
+  } else {
+    if (x->dtype == SFK_BF16) { if (k321) SFK_POOL(bf16_t, 3, 2, 1, false); else SFK_POOL(bf16_t, 0, 0, 0, false); }
+    else SFK_POOL(float, 0, 0, 0, false);
+  }
+#undef SFK_POOL
   SFK_CHECK_LAUNCH();
   return SFK_OK;
+}
+
+extern "C" int sfk_maxpool_fwd(const sfk_fmap* x, const sfk_fmap* y, uint8_t* argmax, int32_t k, int32_t s, int32_t p,
+                               sfk_stream_t stream) {
+  return maxpool_fwd_launch(x, nullptr, nullptr, y, argmax, k, s, p, stream);
+}
+
+extern "C" int sfk_bn_maxpool_fwd(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* out,
+                                  uint8_t* argmax, int32_t k, int32_t s, int32_t p, sfk_stream_t stream) {
+  if (!scale || !shift) return SFK_ERR_INVALID;
+  return maxpool_fwd_launch(y, scale, shift, out, argmax, k, s, p, stream);
 }
 
 extern "C" int sfk_maxpool_bwd(const sfk_fmap* dy, const uint8_t* argmax, const sfk_fmap* dx, int32_t k, int32_t s,

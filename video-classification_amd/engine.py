@@ -158,6 +158,9 @@ class Engine:
         # upper bound: the tail's fixed cost is O(cout * c^2) (T = W G, W^T B W) whatever the map size, what it saves is
         # O(pixels * cout) -- it pays on the large maps of the early stages (c <= 128), not on res4 / res5 (c = 256 / 512)
         self.tail_max_c = int(os.environ.get("SFK_TAIL_MAXC", "128"))
+        # the stems' BatchNorm -> ReLU -> MaxPool as one forward pass and a two-pass backward (sfk_bn_maxpool_*)
+        self.fuse_stem_tail = (os.environ.get("SFK_STEM_TAIL", "1") != "0" and hasattr(self.be, "bn_maxpool_fwd")
+                               and self.be.bn_maxpool_supported(3, 2, 1))
         self.tail_r_lane = os.environ.get("SFK_TAIL_RLANE", "0") == "1"    # R = dz^T a beside the first dgrad pass (_tail_bwd)
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
@@ -569,18 +572,42 @@ class Engine:
         else:
             self._stem_ops(pl, p, x5, t_index)
             pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, L.rm, L.rv, self.spec.bn_eps, L.c, scale, shift))
+        assert (out.h, out.w) == ((y.h + 2 - 3) // 2 + 1, (y.w + 2 - 3) // 2 + 1) and out.t == y.t
+        argmax = self._buf(f"argmax.{p}", out.pixels * L.c, torch.uint8)
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        if self.fuse_stem_tail:
+            # BatchNorm + ReLU + MaxPool in one pass: the activation map (411 MB for the slow stem of the metric) is never
+            # written, and the backward rebuilds its gradient from d_out and the argmax bytes (sfk_bn_maxpool_*)
+            pl.fwd.append(self.be.bn_maxpool_fwd(y, scale, shift, out, argmax, 3, 2, 1), kind="bn_apply",
+                          bytes=float(esz * (y.pixels + out.pixels) * L.c + out.pixels * L.c))
+            return (rec, None, argmax, out, x5, t_index)
         a = self._fmap(f"a.stem{p}", n, y.t, y.h, y.w, L.c)
         self._apply(pl, y, scale, shift, None, None, None, True, a)
-        assert (out.h, out.w) == ((a.h + 2 - 3) // 2 + 1, (a.w + 2 - 3) // 2 + 1) and out.t == a.t
-        argmax = self._buf(f"argmax.{p}", out.pixels * L.c, torch.uint8)
         pl.fwd.append(self.be.maxpool_fwd(a, out, argmax, 3, 2, 1))
         return (rec, a, argmax, out, x5, t_index)
 
     def _stem_bwd(self, pl, p: int, srec, d_out: FMap):
         rec, a, argmax, out, x5, t_index = srec
-        da = self._fmap(f"da.stem{p}", a.n, a.t, a.h, a.w, a.c)
-        pl.bwd.append(self.be.maxpool_bwd(d_out, argmax, da, 3, 2, 1))
-        self._bn_bwd(pl, rec, da, f"stem{p}", True, None, False, da)
+        y, L = rec.y, rec.L
+        da = self._fmap(f"da.stem{p}", y.n, y.t, y.h, y.w, y.c)
+        if a is None:     # fused stem tail: pool routing + ReLU mask + BatchNorm backward in two passes over (d_out, argmax, y)
+            tag = f"stem{p}"
+            esz = 2 if self.dtype == torch.bfloat16 else 4
+            rd = float(esz * (y.pixels + d_out.pixels) * L.c + d_out.pixels * L.c)
+            coef = self._buf(f"coef.{tag}", L.c * 3, torch.float32)
+            parts = self._buf(f"bparts.{tag}", self.max_parts * L.c * 2, torch.float32)
+            run, np_ = self.be.bn_maxpool_bwd_reduce(d_out, argmax, y, rec.mean, rec.invstd, rec.scale, rec.shift, parts,
+                                                     self.max_parts)
+            pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key, bytes=rd)
+            pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
+                                                  self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
+                                                  self._fold_ws(tag, L.c)))
+            pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
+            pl.bwd.append(self.be.bn_maxpool_bwd_apply(d_out, argmax, y, rec.mean, rec.invstd, rec.scale, rec.shift, coef, da),
+                          kind="bn_bwd_apply", layer=L.cb.norm_key, bytes=rd + float(esz * y.pixels * L.c))
+        else:
+            pl.bwd.append(self.be.maxpool_bwd(d_out, argmax, da, 3, 2, 1))
+            self._bn_bwd(pl, rec, da, f"stem{p}", True, None, False, da)
         pl.stem_state[p]["da"] = da
         self._stem_ops(pl, p, x5, t_index)
 
