@@ -766,7 +766,9 @@ def test_conv_masked_store_with_dz_sums_bf16(hip):
     gen = torch.Generator().manual_seed(31)
     emu = EmuBackend()
     dtype = torch.bfloat16
-    for (n, t, h, w, cin, cout, k) in ((2, 2, 9, 7, 16, 40, (3, 1, 1)), (1, 3, 12, 12, 64, 256, (1, 1, 1)), (2, 2, 7, 7, 8, 32, (3, 1, 1))):
+    # (64 -> 256) and (128 -> 512) pointwise: the streaming kernel of conv_pw.hip (one partial row per wave), ragged pixel counts
+    for (n, t, h, w, cin, cout, k) in ((2, 2, 9, 7, 16, 40, (3, 1, 1)), (1, 3, 12, 12, 64, 256, (1, 1, 1)), (2, 2, 7, 7, 8, 32, (3, 1, 1)),
+                                       (3, 5, 21, 19, 64, 256, (1, 1, 1)), (2, 3, 13, 11, 128, 512, (1, 1, 1)), (1, 1, 3, 3, 128, 512, (1, 1, 1))):
         g = ConvGeom(cout, cin, k, (1, 1, 1), (k[0] // 2, 0, 0))            # forward conv cout -> cin; this is its dgrad
         passes, _ = dgrad_passes(g, (t, h, w))
         assert len(passes) == 1
@@ -780,12 +782,14 @@ def test_conv_masked_store_with_dz_sums_bf16(hip):
             dx = FMap(mk((n * t * h * w * cout,), dtype, gen2).to(dev), n, t, h, w, cout)        # the += target
             p = ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(dev), g.wtaps, cin, cout, accumulate=True)
             assert be is emu or (be.conv_relu_out_supported(p) and be.conv_bnb_supported(p))
-            mt = be.conv_igemm_mtiles(p)
-            parts = torch.full((mt * cout * 2,), 7.0, device=dev)
+            parts = torch.full((max(be.conv_igemm_mtiles(p), 1024) * cout * 2,), 7.0, device=dev)
             p.relu_out_bits = bits.to(dev)
             p.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
+            mt = be.conv_igemm_mtiles(p)                 # rows of the descriptor as launched
+            assert 0 < mt <= 1024
             be.conv_igemm(p)(st)
-            outs.append((dx.buf, parts.view(mt, cout, 2)))
+            assert float(parts[mt * cout * 2:].min()) == 7.0     # nothing written past the rows the library announced
+            outs.append((dx.buf, parts[: mt * cout * 2].view(mt, cout, 2)))
         torch.cuda.synchronize()
         (xc, pc), (xg, pg) = outs
         assert rel_err(xg.float().cpu(), xc.float()) < TOL[dtype]

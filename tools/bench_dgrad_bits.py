@@ -9,8 +9,9 @@ from video_classification_amd.plan import ConvGeom, dgrad_passes
 
 be = HipBackend()
 dev = "cuda"
-n, t, h, w, cin, cout = 32, 32, 7, 7, 256, 64
-g = ConvGeom(cin, cout, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+SHAPES = {"fast5": (32, 32, 7, 7, 256, 64, (3, 1, 1)), "slow2": (32, 8, 56, 56, 256, 64, (1, 1, 1)), "slow3": (32, 8, 28, 28, 512, 128, (1, 1, 1))}
+n, t, h, w, cin, cout, kk = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "fast5"]
+g = ConvGeom(cin, cout, kk, (1, 1, 1), (kk[0] // 2, 0, 0))
 sp = dgrad_passes(g, (t, h, w))[0][0]
 px = n * t * h * w
 st = torch.cuda.current_stream().cuda_stream
@@ -19,12 +20,11 @@ st = torch.cuda.current_stream().cuda_stream
 def run(name, dy_t, dx_t, bits_t):
     dy = FMap(dy_t, n, t, h, w, cout)
     dx = FMap(dx_t, n, t, h, w, cin)
-    wt = (torch.randn(cout * 3 * cin, device=dev) * 0.05).bfloat16()
+    wt = (torch.randn(cout * g.wtaps * cin, device=dev) * 0.05).bfloat16()
     for mode in ("plain", "acc", "acc+bits+sum"):
-        cp = ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, 3, cout, cin, accumulate=mode != "plain")
+        cp = ConvPass(dy, dx, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, g.wtaps, cout, cin, accumulate=mode != "plain")
         if mode == "acc+bits+sum":
-            mt = be.conv_igemm_mtiles(cp)
-            parts = torch.zeros(max(mt, 1024) * cin * 2, device=dev)
+            parts = torch.zeros(4096 * cin * 2, device=dev)
             cp.relu_out_bits = bits_t
             cp.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
         r = be.conv_igemm(cp)
@@ -40,7 +40,8 @@ def run(name, dy_t, dx_t, bits_t):
 rnd = lambda c, s=1.0: (torch.randn(px * c, device=dev) * s).bfloat16()
 bits_r = torch.randint(0, 256, (px * cin // 8,), dtype=torch.uint8, device=dev)
 run("randn", rnd(cout), rnd(cin), bits_r)
-run("randn * 1e-30", rnd(cout, 1e-30), rnd(cin, 1e-30), bits_r)
-run("randn * 1e-39 (denormal)", rnd(cout, 1e-39), rnd(cin, 1e-39), bits_r)
-run("zeros", torch.zeros(px * cout, device=dev).bfloat16(), torch.zeros(px * cin, device=dev).bfloat16(), bits_r)
-run("dy with inf/nan", rnd(cout).fill_(float("nan")), rnd(cin), bits_r)
+if len(sys.argv) <= 1:
+    run("randn * 1e-30", rnd(cout, 1e-30), rnd(cin, 1e-30), bits_r)
+    run("randn * 1e-39 (denormal)", rnd(cout, 1e-39), rnd(cin, 1e-39), bits_r)
+    run("zeros", torch.zeros(px * cout, device=dev).bfloat16(), torch.zeros(px * cin, device=dev).bfloat16(), bits_r)
+    run("dy with inf/nan", rnd(cout).fill_(float("nan")), rnd(cin), bits_r)

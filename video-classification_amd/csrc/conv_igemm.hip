@@ -1083,6 +1083,19 @@ inline bool relu_out_ok(const sfk_conv_desc* d) {
 
 inline bool ep_on(const sfk_conv_desc* d) { return d->ep.scale || d->ep.shift; }
 
+// pointwise pass over the pixels of y in order (the streaming kernels of conv_pw.hip)
+inline bool pointwise_lin(const sfk_conv_desc* d) {
+  return d->ntaps == 1 && d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 &&
+         d->gs[2] == 1 && lin_out_of(d) && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w;
+}
+// rows of the streaming data-gradient kernel (accumulate + bitmap mask + column sums), 0 when the pass is not one of its
+inline int pw_dgrad_rows(const sfk_conv_desc* d) {
+  if (d->x.dtype != SFK_BF16 || !sfk_tune().igemm_pw_stream || (sfk_tune().igemm_pw_stream & 4) || !d->accumulate || ep_on(d) || d->stats || !d->out_relu_bits ||
+      !d->bnb.partials || d->bnb.y_bn.ptr || !pointwise_lin(d) || !bnb_ok(d))
+    return 0;
+  return sfk_conv_pw_dgrad_rows(d);
+}
+
 int validate(const sfk_conv_desc* d) {
   if (!d || !d->w) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
@@ -1228,6 +1241,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       const int r = sfk_conv_pw_fused(d, s);
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
+    if (pw_dgrad_rows(d) > 0) return sfk_conv_pw_dgrad(d, s);
   }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
@@ -1280,6 +1294,8 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
 extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   const int st = validate(d);
   if (st != SFK_OK) return st;
+  const int rows = pw_dgrad_rows(d);      // the streaming data-gradient kernel leaves one row per wave of a co group
+  if (rows > 0) return rows;
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
   const int bm = pick_tile(d).bm;
   return (int)((M + bm - 1) / bm);

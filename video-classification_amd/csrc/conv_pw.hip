@@ -11,6 +11,13 @@
 //   * software pipeline one tile deep: the loads of tile i+1 (X and the shortcut rows, up to 12 x 16 B per lane) are in
 //     flight while tile i runs its MFMAs and its epilogue; 8 waves per CU keep ~80 KB in flight;
 //   * epilogue as conv_igemm's: v_permlane16_swap pairs -> 8 consecutive channels per lane -> 16-byte stores.
+//
+// DG = true is the same machine as a DATA-GRADIENT pass of a pointwise conv_a whose result finishes the gradient of the
+// previous block's output (sfk_conv_desc: accumulate + out_relu_bits + bnb with y_bn = NULL):
+//     dX[pix][ci] = (dX[pix][ci] + sum_k dY[pix][k] Wt[ci][k]) * bit[pix][ci]      and the column sums of the STORED values
+// -- K = 64 / 128 only, so the implicit-GEMM kernel's tile lives for 2..4 K-steps and is all epilogue (335 us for 0.95 GB on
+// slow res2); here the old rows and the bitmap bytes are prefetched one tile ahead like the shortcut of the forward, and
+// every wave leaves ONE partial row [cout][2] = (sum, 0): sfk_conv_igemm_mtiles reports the number of waves per co group.
 #include "sfk_common.h"
 
 namespace {
@@ -22,6 +29,8 @@ struct PwK {
   const void* res;
   const float *scale, *shift, *rscale, *rshift;
   uint8_t* bits;
+  const uint8_t* mbits;        // DG: the ReLU bitmap to multiply by
+  float* parts;                // DG: partial rows [waves per co group][cout][2]
   int xld, xoff, yld, yoff, rld, roff;
   int M, K, cout, relu;
   uint32_t xbytes, ybytes, rbytes;
@@ -40,7 +49,7 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
 // NT: threads per workgroup (512 when the filter leaves room for ONE workgroup per CU: still 2 waves per SIMD);
 // XDB: the next tile's X rows have registers of their own (else they are fetched into the current ones once the MFMAs
 // have consumed them: KS = 4 would spill otherwise)
-template <int NF, int KS, int CG, int NT, bool XDB>
+template <int NF, int KS, int CG, int NT, bool XDB, bool DG = false>
 __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
   constexpr int CW = NF * 16;                 // channels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
       const uint4 v = sfk_buffer_load16(wrs, kk < k.K ? (uint32_t)((r * k.K + kk) * 2) : SFK_OOB);
       *reinterpret_cast<uint4*>(wl + ks * k.cout * 64 + slab_off(r, s)) = v;
     }
-    for (int i = tid; i < k.cout; i += NT) {
+    if (!DG) for (int i = tid; i < k.cout; i += NT) {
       coef[i] = k.scale ? k.scale[i] : 1.f;
       coef[k.cout + i] = (k.shift ? k.shift[i] : 0.f) + ((k.res && k.rshift) ? k.rshift[i] : 0.f);
       coef[2 * k.cout + i] = (k.res && k.rscale) ? k.rscale[i] : 1.f;
@@ -80,6 +89,14 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
 
   uint4 xc[KS], xn[XDB ? KS : 1];
   uint4 rc[NF / 2], rn[NF / 2];
+  uint32_t mc[DG ? NF / 2 : 1], mn[DG ? NF / 2 : 1];      // DG: bitmap bytes of the 8-channel groups this lane stores
+  float csum[DG ? NF / 2 : 1][8];
+  if constexpr (DG) {
+#pragma unroll
+    for (int p = 0; p < NF / 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum[p][e] = 0.f;
+  }
   auto issue_x = [&](int tile, uint4 (&xv)[KS]) __attribute__((always_inline)) {
     int m = tile * 16 + l15;
     if (m >= k.M) m = k.M - 1;                                   // ragged last tile: re-read the last row (not stored)
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
       xv[ks] = sfk_buffer_load16(xrs, kk < k.K ? xrow + (uint32_t)(kk * 2) : SFK_OOB);
     }
   };
-  auto issue_r = [&](int tile, uint4 (&rv)[NF / 2]) __attribute__((always_inline)) {
+  auto issue_r = [&](int tile, uint4 (&rv)[NF / 2], uint32_t (&mv)[DG ? NF / 2 : 1]) __attribute__((always_inline)) {
     if (has_res) {
       int m = tile * 16 + l15;
       if (m >= k.M) m = k.M - 1;
@@ -98,19 +115,26 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
 #pragma unroll
       for (int p = 0; p < NF / 2; ++p)
         rv[p] = sfk_buffer_load16(rrs, rrow + (uint32_t)((32 * p + 16 * (g & 1) + 8 * (g >> 1)) * 2));
+      if constexpr (DG) {
+#pragma unroll
+        for (int p = 0; p < NF / 2; ++p)
+          mv[p] = k.mbits[(int64_t)m * (k.cout >> 3) + ((co_w + 32 * p + 16 * (g & 1) + 8 * (g >> 1)) >> 3)];
+      }
     }
   };
 
   int tile = wi;
-  if (tile >= ntiles) return;
-  issue_x(tile, xc);
-  issue_r(tile, rc);
+  if (!DG && tile >= ntiles) return;
+  if (tile < ntiles) {
+    issue_x(tile, xc);
+    issue_r(tile, rc, mc);
+  }
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
   for (; tile < ntiles; tile += nw) {
     const int nxt = tile + nw;
     if (nxt < ntiles) {
       if constexpr (XDB) issue_x(nxt, reinterpret_cast<uint4(&)[KS]>(xn));
-      issue_r(nxt, rn);
+      issue_r(nxt, rn, mn);
     }
     // ---- MFMAs: A = filter fragment (rows = co) from LDS, B = the pixel fragment in registers
     f32x4 acc[NF];
@@ -139,6 +163,18 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) swap16f(v[e], v[4 + e]);
       const int co = co_w + 32 * p + 16 * (g & 1) + 8 * (g >> 1);
+      if constexpr (DG) {
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rc[p]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = ((mc[p] >> e) & 1u) ? v[e] + (float)r8[e] : 0.f;
+          o[e] = (bf16_t)f;
+          if (rok) csum[p][e] += (float)o[e];        // sums of what is STORED (what the consumer reads back)
+        }
+        if (rok) *reinterpret_cast<bf16x8*>(yp + yrow + co) = o;
+        continue;
+      }
       const float4 s0 = *reinterpret_cast<const float4*>(coef + co), s1 = *reinterpret_cast<const float4*>(coef + co + 4);
       const float4 h0 = *reinterpret_cast<const float4*>(coef + k.cout + co), h1 = *reinterpret_cast<const float4*>(coef + k.cout + co + 4);
       const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -174,26 +210,56 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
     }
 #pragma unroll
     for (int p = 0; p < NF / 2; ++p) rc[p] = rn[p];
+    if constexpr (DG) {
+#pragma unroll
+      for (int p = 0; p < NF / 2; ++p) mc[p] = mn[p];
+    }
+  }
+  if constexpr (DG) {
+    // this wave's partial row: fold the 16 pixel lanes (fixed butterfly order), lanes l15 == 0 write 8 channels each
+    float* row = k.parts + (int64_t)wi * k.cout * 2;
+#pragma unroll
+    for (int p = 0; p < NF / 2; ++p) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[p][e];
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 8);
+        csum[p][e] = t;
+      }
+      if (l15 == 0) {
+        const int co = co_w + 32 * p + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<float2*>(row + (co + e) * 2) = make_float2(csum[p][e], 0.f);
+      }
+    }
   }
 }
 
-template <int NF, int KS, int CG, int NT, bool XDB>
+// workgroups of a launch: one resident generation (8 waves per CU either way), every co group the same number of waves
+inline int pw_blocks(int M, int CG, int NT) {
+  const int WPB = NT / 64;
+  const int ntiles = (M + 15) / 16;
+  int blocks = 256 * (NT == 512 ? 1 : 2);
+  const int need = (ntiles * CG + WPB - 1) / WPB;
+  if (blocks > need) blocks = need;
+  while ((blocks * WPB) % CG) ++blocks;
+  return blocks;
+}
+
+template <int NF, int KS, int CG, int NT, bool XDB, bool DG = false>
 int pw_launch(const PwK& k, hipStream_t s) {
-  constexpr int WPB = NT / 64;
   const size_t lds = (size_t)KS * k.cout * 64 + (size_t)3 * k.cout * 4;
   static bool attr_set = false;             // > 64 KB of dynamic LDS needs the opt-in (idempotent, set once per process)
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG, NT, XDB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG, NT, XDB, DG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SFK_ERR_LAUNCH;
     attr_set = true;
   }
-  const int ntiles = (k.M + 15) / 16;
-  int blocks = 256 * (NT == 512 ? 1 : 2);               // one resident generation: 8 waves per CU either way
-  const int need = (ntiles * CG + WPB - 1) / WPB;
-  if (blocks > need) blocks = need;
-  while ((blocks * WPB) % CG) ++blocks;                 // every co group gets the same number of waves
-  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG, NT, XDB>), dim3(blocks), dim3(NT), lds, s, k);
+  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG, NT, XDB, DG>), dim3(pw_blocks(k.M, CG, NT)), dim3(NT), lds, s, k);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -211,7 +277,7 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   PwK k;
   k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.res = e.res.ptr;
   k.scale = e.scale; k.shift = e.shift; k.rscale = e.res_scale; k.rshift = e.res_shift;
-  k.bits = e.relu_bits;
+  k.bits = e.relu_bits; k.mbits = nullptr; k.parts = nullptr;
   k.xld = d->x.ld; k.xoff = d->x.c_off; k.yld = d->y.ld; k.yoff = d->y.c_off;
   k.rld = e.res.ptr ? e.res.ld : 0; k.roff = e.res.ptr ? e.res.c_off : 0;
   k.M = (int)sfk_fmap_pixels(&d->y); k.K = K; k.cout = C; k.relu = e.relu;
@@ -226,5 +292,27 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   // 134 KB of filter: one 8-wave workgroup per CU; 64 channels per wave (8 fragments at KS = 4 spill), the eight co groups
   // of a workgroup read the same X rows (L1)
   if (C == 512 && KS == 4) return pw_launch<4, 4, 8, 512, true>(k, s);
+  return SFK_ERR_UNSUPPORTED;
+}
+
+// The data-gradient flavour (DG): shapes (dY channels -> dX channels) (64 -> 256) and (128 -> 512), the pointwise conv_a of the
+// slow pathway's res2 / res3.  sfk_conv_pw_dgrad_rows: partial rows such a launch leaves (0: not a shape of this kernel).
+int sfk_conv_pw_dgrad_rows(const sfk_conv_desc* d) {
+  const int M = (int)sfk_fmap_pixels(&d->y);
+  if (d->cin == 64 && d->cout == 256) return pw_blocks(M, 2, 256) * 4 / 2;
+  if (d->cin == 128 && d->cout == 512) return pw_blocks(M, 8, 512) * 8 / 8;
+  return 0;
+}
+
+int sfk_conv_pw_dgrad(const sfk_conv_desc* d, hipStream_t s) {
+  PwK k;
+  k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.res = d->y.ptr;          // in place: old rows + result
+  k.scale = k.shift = k.rscale = k.rshift = nullptr;
+  k.bits = nullptr; k.mbits = d->out_relu_bits; k.parts = d->bnb.partials;
+  k.xld = d->x.ld; k.xoff = d->x.c_off; k.yld = d->y.ld; k.yoff = d->y.c_off; k.rld = d->y.ld; k.roff = d->y.c_off;
+  k.M = (int)sfk_fmap_pixels(&d->y); k.K = d->cin; k.cout = d->cout; k.relu = 0;
+  k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y); k.rbytes = k.ybytes;
+  if (d->cin == 64 && d->cout == 256) return pw_launch<8, 2, 2, 256, true, true>(k, s);
+  if (d->cin == 128 && d->cout == 512) return pw_launch<4, 4, 8, 512, true, true>(k, s);
   return SFK_ERR_UNSUPPORTED;
 }

@@ -506,6 +506,10 @@ class Engine:
                     parts = self._buf(f"bparts.{out_sum_tag}.c", max(mt, self.max_parts) * L.eg.cin * 2, torch.float32)
                     cp.relu_out_bits = out_bits
                     cp.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
+                    # the row count is a property of the descriptor AS LAUNCHED (the streaming pointwise kernel leaves one
+                    # row per wave, at most max_parts): ask again now that the epilogue is set
+                    mt = self.be.conv_igemm_mtiles(cp)
+                    assert mt <= max(mt, self.max_parts) and parts.numel() >= mt * L.eg.cin * 2
                     reduced = ("masked+sum", parts, mt)
                     extra = float(rows * L.eg.cin // self.kvec)
             elif out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp):
