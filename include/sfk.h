@@ -142,8 +142,9 @@ typedef struct {
 } sfk_conv_desc;
 
 int sfk_conv_igemm(const sfk_conv_desc* d, sfk_stream_t stream);
-int sfk_conv_igemm_mtiles(const sfk_conv_desc* d); /* rows of d->stats / d->bnb.partials for d AS IT WILL BE LAUNCHED (the
-                                                      kernel family, hence the row count, depends on the epilogue fields); <0 on error */
+/* rows of d->stats / d->bnb.partials; <0 on error.  The kernel family, hence the row count, can depend on the epilogue
+ * fields: for bnb / out_relu_bits ask with the descriptor as it will be launched (`stats` rows do not depend on them). */
+int sfk_conv_igemm_mtiles(const sfk_conv_desc* d);
 int sfk_conv_bnb_supported(const sfk_conv_desc* d);  /* 1 if d (ignoring d->bnb) can run with the bnb fusion, else 0 */
 int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out_relu_bits) can apply a bitmap, else 0 */
 int sfk_conv_epilogue_supported(const sfk_conv_desc* d); /* 1 if d's ep (as filled in) can run, else 0 */

@@ -759,6 +759,46 @@ def test_conv_epilogue_variants(hip, dtype):
     assert not hip.conv_epilogue_supported(p)            # ReLU needs two co fragments per wave in bf16 (cout > 16)
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (128, 128), (256, 64)], ids=str)
+def test_conv_pointwise_streaming_plain_bf16(hip, shape):
+    """the streaming pointwise kernel (conv_pw.hip) behind sfk_conv_igemm for the K = cout = 64 / 128 passes of the block tail's
+    backward: store, +=, += with a bias; with BatchNorm partial rows (and for other shapes) the implicit GEMM runs"""
+    from video_classification_amd._lib import ConvEpilogue
+    cin, cout = shape
+    gen = torch.Generator().manual_seed(cin + cout)
+    emu = EmuBackend()
+    dtype = torch.bfloat16
+    n, t, h, w = 2, 3, 13, 11                                     # 858 pixels: ragged last 16-pixel tile
+    one, tap0 = (1, 1, 1), [(0, 0, 0, 0)]
+    wt = mk((cout * cin,), dtype, gen, scale=cin ** -0.5)
+    bias = torch.randn(cout, generator=gen)
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    for mode in ("stats", "plain", "acc", "acc+bias"):
+        yc, yg = fmap_pair(n, cout, t, h, w, dtype, gen, ld=cout + 8, c_off=8)
+        res = []
+        for be, x, y, dev in ((emu, xc, yc, "cpu"), (hip, xg, yg, DEV)):
+            p = ConvPass(x, y, (t, h, w), one, one, (0, 0, 0), tap0, wt.to(dev), 1, cin, cout, accumulate=mode.startswith("acc"))
+            if mode == "acc+bias":
+                p.ep = ConvEpilogue(shift=bias.to(dev))
+            mt = 0
+            if mode == "stats":
+                mt = be.conv_igemm_mtiles(p)
+                p.stats = torch.full((mt * cout * 2 + 64,), 5.0, device=dev)
+                assert be.conv_igemm_mtiles(p) == mt                 # same answer once the pointer is set
+            if be is hip:
+                assert (be.conv_family(p) == 3) == (mode != "stats" and cin == cout)
+            be.conv_igemm(p)(stream() if dev != "cpu" else 0)
+            if dev != "cpu":
+                torch.cuda.synchronize()
+            res.append((y.buf.float().cpu(), None if not mt else p.stats.cpu()[: mt * cout * 2].view(mt, cout, 2), mt,
+                        None if not mt else p.stats.cpu()[mt * cout * 2:]))
+        (yc_, sc_, _, _), (yg_, sg_, mtg, tailg) = res
+        assert rel_err(yg_, yc_) < TOL[dtype], mode
+        assert torch.equal(yg_.view(-1, cout + 8)[:, :8], yc_.view(-1, cout + 8)[:, :8])      # the neighbouring slice is untouched
+        if mode == "stats":
+            assert rel_err(sg_.sum(0), sc_.sum(0)) < 1e-4 and float(tailg.min()) == 5.0 == float(tailg.max())
+
+
 def test_conv_masked_store_with_dz_sums_bf16(hip):
     """sfk_bn_bwd_fuse with y_bn = NULL + out_relu_bits: the data-gradient pass that finishes a block's output gradient
     stores dz = (old + result) * bitmap and leaves the per-tile partial sums of the STORED dz (what sfk_bn_tail_bwd folds)"""

@@ -1088,6 +1088,14 @@ inline bool pointwise_lin(const sfk_conv_desc* d) {
   return d->ntaps == 1 && d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 &&
          d->gs[2] == 1 && lin_out_of(d) && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w;
 }
+// plain / += / + bias pointwise passes with K = cout = 64 / 128 (the second data-gradient pass of the block tail's backward on
+// slow res2 / res3): streaming kernel of conv_pw.hip
+inline bool pw_plain_route(const sfk_conv_desc* d) {
+  if (d->x.dtype != SFK_BF16 || !sfk_tune().igemm_pw_stream || (sfk_tune().igemm_pw_stream & 8) || d->stats || d->bnb.partials ||
+      d->out_relu_bits || d->ep.res.ptr || d->ep.relu || d->ep.scale || !pointwise_lin(d) || (d->y.ld % 8) || (d->y.c_off % 8))
+    return false;
+  return (d->cout == 64 && d->cin == 64) || (d->cout == 128 && d->cin == 128);
+}
 // rows of the streaming data-gradient kernel (accumulate + bitmap mask + column sums), 0 when the pass is not one of its
 inline int pw_dgrad_rows(const sfk_conv_desc* d) {
   if (d->x.dtype != SFK_BF16 || !sfk_tune().igemm_pw_stream || (sfk_tune().igemm_pw_stream & 4) || !d->accumulate || ep_on(d) || d->stats || !d->out_relu_bits ||
@@ -1242,6 +1250,10 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
     if (pw_dgrad_rows(d) > 0) return sfk_conv_pw_dgrad(d, s);
+    if (pw_plain_route(d)) {
+      const int r = sfk_conv_pw_fused(d, s);
+      if (r != SFK_ERR_UNSUPPORTED) return r;
+    }
   }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
@@ -1317,6 +1329,8 @@ extern "C" int sfk_conv_igemm_family(const sfk_conv_desc* d) {
         lin_out_of(d) && d->x.t == d->y.t && d->x.h == d->y.h && d->x.w == d->y.w && d->cin <= 128 &&
         ((d->cout == 32 || d->cout == 64 || d->cout == 128) ? d->cin <= 32 : (d->cout == 256 ? (d->cin > 32 && d->cin <= 64) : (d->cout == 512 && d->cin > 96))))
       return 3;
+    if (pw_dgrad_rows(d) > 0) return 3;
+    if (pw_plain_route(d)) return 3;
   }
   return pick_tile(d).dma ? 1 : 0;
 }

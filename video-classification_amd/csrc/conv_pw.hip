@@ -30,7 +30,7 @@ struct PwK {
   const float *scale, *shift, *rscale, *rshift;
   uint8_t* bits;
   const uint8_t* mbits;        // DG: the ReLU bitmap to multiply by
-  float* parts;                // DG: partial rows [waves per co group][cout][2]
+  float* parts;                // DG: partial rows [waves per co group][cout][2] = (sum, 0)
   int xld, xoff, yld, yoff, rld, roff;
   int M, K, cout, relu;
   uint32_t xbytes, ybytes, rbytes;
@@ -49,8 +49,13 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
 // NT: threads per workgroup (512 when the filter leaves room for ONE workgroup per CU: still 2 waves per SIMD);
 // XDB: the next tile's X rows have registers of their own (else they are fetched into the current ones once the MFMAs
 // have consumed them: KS = 4 would spill otherwise)
-template <int NF, int KS, int CG, int NT, bool XDB, bool DG = false>
+// MODE 0: fused output transform (plain / += / + bias passes included: scale = 1, shortcut = the old rows); 1 (DG): data
+// gradient, see above.  (A third flavour -- plain store + BatchNorm partial rows for K = 256 / 512 -> 64 / 128, the forward
+// conv_a of slow res2 / res3 -- measured SLOWER than the implicit GEMM, 129 vs 119 us: 32 filter fragments per 16-pixel tile
+// no longer fit in registers and are re-read from LDS; it was removed.)
+template <int NF, int KS, int CG, int NT, bool XDB, int MODE = 0>
 __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
+  constexpr bool DG = MODE == 1;
   constexpr int CW = NF * 16;                 // channels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wl = smem;                            // KS slabs of [cout][32]
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
       const uint4 v = sfk_buffer_load16(wrs, kk < k.K ? (uint32_t)((r * k.K + kk) * 2) : SFK_OOB);
       *reinterpret_cast<uint4*>(wl + ks * k.cout * 64 + slab_off(r, s)) = v;
     }
-    if (!DG) for (int i = tid; i < k.cout; i += NT) {
+    if (MODE == 0) for (int i = tid; i < k.cout; i += NT) {
       coef[i] = k.scale ? k.scale[i] : 1.f;
       coef[k.cout + i] = (k.shift ? k.shift[i] : 0.f) + ((k.res && k.rshift) ? k.rshift[i] : 0.f);
       coef[2 * k.cout + i] = (k.res && k.rscale) ? k.rscale[i] : 1.f;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
   };
 
   int tile = wi;
-  if (!DG && tile >= ntiles) return;
+  if (MODE == 0 && tile >= ntiles) return;
   if (tile < ntiles) {
     issue_x(tile, xc);
     issue_r(tile, rc, mc);
@@ -140,12 +145,17 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
     f32x4 acc[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The filter fragments do not depend on the tile: with few of them the compiler keeps them in registers across tiles
+    // (no LDS traffic in the loop); 32 or more (128+ VGPRs) would spill, so there the LDS base is laundered per tile and
+    // the fragments are re-read (LDS time stays under the tile's HBM time: 32 KB per 16 x K x 2 B of pixels)
+    const char* wlt = wl;
+    if constexpr (NF * KS >= 32) asm volatile("" : "+v"(wlt));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 b = __builtin_bit_cast(bf16x8, xc[ks]);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + ks * k.cout * 64 + slab_off(co_w + 16 * i + l15, g));
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(wlt + ks * k.cout * 64 + slab_off(co_w + 16 * i + l15, g));
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
       }
     }
@@ -223,10 +233,8 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_fused_kernel(const PwK k) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = csum[p][e];
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 4);
-        t += __shfl_xor(t, 8);
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) t += __shfl_xor(t, sft);
         csum[p][e] = t;
       }
       if (l15 == 0) {
@@ -249,17 +257,17 @@ inline int pw_blocks(int M, int CG, int NT) {
   return blocks;
 }
 
-template <int NF, int KS, int CG, int NT, bool XDB, bool DG = false>
+template <int NF, int KS, int CG, int NT, bool XDB, int MODE = 0>
 int pw_launch(const PwK& k, hipStream_t s) {
   const size_t lds = (size_t)KS * k.cout * 64 + (size_t)3 * k.cout * 4;
   static bool attr_set = false;             // > 64 KB of dynamic LDS needs the opt-in (idempotent, set once per process)
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG, NT, XDB, DG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_fused_kernel<NF, KS, CG, NT, XDB, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SFK_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG, NT, XDB, DG>), dim3(pw_blocks(k.M, CG, NT)), dim3(NT), lds, s, k);
+  hipLaunchKernelGGL((conv_pw_fused_kernel<NF, KS, CG, NT, XDB, MODE>), dim3(pw_blocks(k.M, CG, NT)), dim3(NT), lds, s, k);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -283,6 +291,13 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   k.M = (int)sfk_fmap_pixels(&d->y); k.K = K; k.cout = C; k.relu = e.relu;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
   k.rbytes = e.res.ptr ? (uint32_t)sfk_fmap_bytes(&e.res) : 0u;
+  if (d->accumulate) {          // y += : the old rows come in as the shortcut of the output transform
+    if (k.res) return SFK_ERR_UNSUPPORTED;
+    k.res = d->y.ptr; k.rld = d->y.ld; k.roff = d->y.c_off; k.rbytes = k.ybytes;
+  }
+  // plain / += / + bias passes of the block tail's backward with K = C (64.6 -> 45.4 us on slow res2: 6.8 TB/s)
+  if (C == 64 && KS == 2) return pw_launch<4, 2, 1, 256, true>(k, s);
+  if (C == 128 && KS == 4) return pw_launch<8, 4, 1, 256, true>(k, s);
   if (C == 32 && KS == 1) return pw_launch<2, 1, 1, 256, true>(k, s);
   if (C == 64 && KS == 1) return pw_launch<4, 1, 1, 256, true>(k, s);
   if (C == 128 && KS == 1) return pw_launch<8, 1, 1, 256, true>(k, s);
@@ -312,7 +327,7 @@ int sfk_conv_pw_dgrad(const sfk_conv_desc* d, hipStream_t s) {
   k.xld = d->x.ld; k.xoff = d->x.c_off; k.yld = d->y.ld; k.yoff = d->y.c_off; k.rld = d->y.ld; k.roff = d->y.c_off;
   k.M = (int)sfk_fmap_pixels(&d->y); k.K = d->cin; k.cout = d->cout; k.relu = 0;
   k.xbytes = (uint32_t)sfk_fmap_bytes(&d->x); k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y); k.rbytes = k.ybytes;
-  if (d->cin == 64 && d->cout == 256) return pw_launch<8, 2, 2, 256, true, true>(k, s);
-  if (d->cin == 128 && d->cout == 512) return pw_launch<4, 4, 8, 512, true, true>(k, s);
+  if (d->cin == 64 && d->cout == 256) return pw_launch<8, 2, 2, 256, true, 1>(k, s);
+  if (d->cin == 128 && d->cout == 512) return pw_launch<4, 4, 8, 512, true, 1>(k, s);
   return SFK_ERR_UNSUPPORTED;
 }

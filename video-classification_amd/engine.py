@@ -367,7 +367,7 @@ class Engine:
         p = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), w, L.eg.wtaps, L.eg.cin, L.eg.cout)
         stats, mt = None, 0
         if stats_tag is not None:
-            mt = self.be.conv_igemm_mtiles(p)
+            mt = self.be.conv_igemm_mtiles(p)       # rows the pass will leave in `stats` (kernel-family specific)
             stats = self._buf(stats_tag, mt * L.c * 2, torch.float32)
             p.stats = stats
         rows = x.n * sp.rows[0] * sp.rows[1] * sp.rows[2]
