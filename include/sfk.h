@@ -433,7 +433,8 @@ typedef struct {
   int32_t nt_bwd_apply_mb;    /* 150:  non-temporal loads+stores in sfk_bn_bwd_apply                              */
   int32_t igemm_pw_stream;    /* 1:    streaming kernel for small-filter pointwise convs with a fused shortcut / ReLU     */
   int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
-  int32_t igemm_tile256;      /* 1:    256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs       */
+  int32_t igemm_tile256;      /* 3:    bit 0: 256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs;
+                                         bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
   int32_t reserved;
 } sfk_tuning;
 void sfk_default_tuning(sfk_tuning* out);

@@ -60,6 +60,8 @@ CONV_CASES = [
     (128, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 14, 14)),  # 14x14 frames, 2 ci tiles
     (64, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 120, 160)),  # 600 row tiles: more tiles than resident workgroups (persistent kernel: several tiles per block)
     (32, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 5, 96, 112)),  # 630 x 2 tiles, 3 taps, ragged last tile
+    (512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 70, 72)),   # 256-channel LDS-DMA tile with 224 computed rows (180 tiles: one generation), ragged
+    (256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 4, 64, 64)),   # 256 x 256 tile (exactly 256 tiles), 3 taps
 ]
 
 

@@ -822,12 +822,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
 //     s_barrier per K-step (never a full drain).
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int BM, int BN, int WM, int WN, int EPI = 0>
+// BMS: pixel rows a tile COMPUTES (= the tile stride over M); BM rows are staged.  BMS < BM (224 of 256, waves as 2 x 4 with
+// 7 row fragments each) exists for the tile-count arithmetic: M = 50,176 (res4) is 196 tiles of 256 rows -- 0.77 of one
+// generation on 256 CUs -- but 224 tiles of 224 rows; the 32 extra staged rows cost L2 -> LDS traffic an MFMA-bound layer has.
+template <int BM, int BN, int WM, int WN, int EPI = 0, int BMS = BM>
 __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 3))) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
   constexpr int VEC = 8, SEGS = 4, ROWB = 64;
-  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  constexpr int FM = BMS / WM / 16, FN = BN / WN / 16;
+  static_assert(BMS <= BM && BMS % (16 * WM) == 0, "computed rows");
   constexpr int NW = WM * WN;                  // waves per block (4 or 8)
   constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;   // every wave issues the same number of filter DMAs (rows >= BN are OOB)
   constexpr int XI = BM / (16 * NW), WI = WROWS / (16 * NW);   // DMA wave-instructions per wave per K-step
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
   uint32_t xbase[XI];
 #pragma unroll
   for (int j = 0; j < XI; ++j) {
-    const int m = mt * BM + wave * (BM / NW) + 16 * j + lrow;
+    const int m = mt * BMS + wave * (BM / NW) + 16 * j + lrow;
     uint32_t q1, rw_, q2, rh_, n_, rt_;
     k.drw.divmod((uint32_t)m, q1, rw_);
     k.drh.divmod(q1, q2, rh_);
@@ -968,14 +972,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   ResPre<(EPI == 4 ? FM : 1), (EPI == 4 ? FN : 2)> respre;
-  if constexpr (EPI == 4) prefetch_res<T, FM, FN, BM, BN, WM, WN>(k, respre, mt, nt, wm, wn, lane);
+  if constexpr (EPI == 4) prefetch_res<T, FM, FN, BMS, BN, WM, WN>(k, respre, mt, nt, wm, wn, lane);
 
   // fragment addresses inside a ring slot are loop-invariant; the slot base is a compile-time constant (ring unrolled)
   int a_off[FN], b_off[FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i) a_off[i] = BM * ROWB + TL::off(wn * (BN / WN) + 16 * i + l15, g);
 #pragma unroll
-  for (int j = 0; j < FM; ++j) b_off[j] = TL::off(wm * (BM / WM) + 16 * j + l15, g);
+  for (int j = 0; j < FM; ++j) b_off[j] = TL::off(wm * (BMS / WM) + 16 * j + l15, g);
   auto compute = [&](int slot_base) {
     TL::frag a[FN], b[FM];
 #pragma unroll
@@ -1019,18 +1023,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
 
   // ---- epilogue
   if constexpr (EPI == 1) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
-    epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    epilogue_bn_bwd<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
   if constexpr (EPI == 3) {
-    epilogue_fused<T, FM, FN, BM, BN, WM, WN>(k, acc, mt, nt, wm, wn, lane);
+    epilogue_fused<T, FM, FN, BMS, BN, WM, WN>(k, acc, mt, nt, wm, wn, lane);
     return;
   }
   if constexpr (EPI == 4) {
-    epilogue_fused<T, FM, FN, BM, BN, WM, WN, true>(k, acc, mt, nt, wm, wn, lane, &respre);
+    epilogue_fused<T, FM, FN, BMS, BN, WM, WN, true>(k, acc, mt, nt, wm, wn, lane, &respre);
     return;
   }
-  epilogue_plain<T, EPI, FM, FN, BM, BN, WM, WN, false>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+  epilogue_plain<T, EPI, FM, FN, BMS, BN, WM, WN, false>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
 }
 
 struct TileSel { int bm, bn; bool dma; };
@@ -1053,8 +1057,11 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
     // Measured (res4, M = 50,176): 1024 -> 256 (3,1,1) 775 -> 863 TFLOP/s, 256 -> 256 (1,3,3) data gradient 844 -> 882; with
     // 1024 output channels (784 workgroups, one per CU: 3.06 generations) 810 -> 713 -- so only where ONE tile spans cout.
     if (sfk_tune().igemm_tile256 && cout == 256 && ktot >= 512 && M >= 256 * 128 && !d->ep.scale && !d->ep.shift &&
-        !d->bnb.partials && !d->out_relu_bits)
-      return {256, 256, true};
+        !d->bnb.partials && !d->out_relu_bits) {
+      // one workgroup per CU: 224 computed rows per tile when that needs fewer row-generations x rows than 256
+      const int64_t g256 = ((M + 255) / 256 + 255) / 256 * 256, g224 = ((M + 223) / 224 + 255) / 256 * 224;
+      return {(sfk_tune().igemm_tile256 & 2) && g224 < g256 ? 224 : 256, 256, true};
+    }
     if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr) return {256, 128, true};
     return {128, 128, true};
   }
@@ -1173,7 +1180,8 @@ int validate(const sfk_conv_desc* d) {
 
 int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
   if (bn == 256) {
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, k);
+    if (bm == 224) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 2, 4, 0, 224>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
