@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--classes", type=int, default=400)
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (serialises the two pathway streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="one GPU: run the N>1 backward schedule (segments + comm stream) with a local stand-in for the all-reduce; "
+                         "a diagnostic of what the fifth stream costs, the line is marked and is not the metric")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-stages", action="store_true", help="also report every kernel class timed alone on one stream")
     args = ap.parse_args()
@@ -206,6 +209,8 @@ def main():
     labels = torch.randint(0, args.classes, (B,), generator=gen).to(dev)
     idx = pack_pathway_index(32, 4, dev)                   # slow pathway = frames [0,4,8,13,17,22,26,31]
     reducer = sdist.GradReducer(eng.G, bucket_mb=32.0) if world > 1 else None
+    if world == 1 and args.rehearse_comm:
+        reducer = sdist.LoopbackReducer(eng.G, world=8, bucket_mb=32.0)     # NOT the metric: see --rehearse-comm
     step = TrainStep(eng, lr=2e-4, use_graph=args.graph, reducer=reducer)
 
     def barrier():
@@ -239,6 +244,9 @@ def main():
                    "params": eng.num_parameters()},
         "loss_after": round(final_loss, 4),
     }
+    if world == 1 and args.rehearse_comm:
+        line["rehearsal"] = ("NOT the metric: the N = 8 backward schedule on one GPU with a local stand-in for every all-reduce "
+                             "bucket (dist.LoopbackReducer); GPU_MAX_HW_QUEUES=" + os.environ.get("GPU_MAX_HW_QUEUES", "default"))
     if rank == 0 and not args.no_roofline:
         pl = eng._plan_for(frames, frames, idx, True)
         # the roofline numbers come from the PRODUCTION schedule (4 lanes); SFK_PER_LAYER additionally dumps the serial view

@@ -13,10 +13,3 @@ Layout:
   dist.py      one-process-per-GPU gradient all-reduce over RCCL
 """
 __version__ = "0.1.0"
-
-import os as _os
-
-if int(_os.environ.get("WORLD_SIZE", "1")) > 1:
-    # multi-rank job: a fifth hardware queue for the gradient all-reduce's stream (dist.reserve_comm_queue), set here because
-    # the HIP runtime reads it once, at its first call
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -18,21 +18,12 @@ import torch.utils.data
 Range = Tuple[int, int]  # (offset, numel) in the arena
 
 
-def reserve_comm_queue():
-    """A process gets 4 hardware queues by default and the step's four lanes use them all (engine.Engine.NLANES): the
-    gradient all-reduce's stream would share a queue with a compute lane and serialise with it.  GPU_MAX_HW_QUEUES is read
-    when the HIP runtime initialises, so this only helps before the first device call (bench.py and Trainer call it first);
-    measured neutral on one GPU (1065 vs 1063 clips/s at 4 vs 8 queues)."""
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-
 def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's environment; no-op for a single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        reserve_comm_queue()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -112,6 +103,37 @@ class GradReducer:
         if self.world > 1 and self.cuda:
             torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
         return 1.0 / self.world
+
+
+class LoopbackReducer(GradReducer):
+    """Single-process REHEARSAL of the overlapped gradient exchange (bench.py --rehearse-comm): the same segment cuts, event
+    waits, comm stream and bucket sizes as GradReducer with world ranks, but each bucket's all-reduce is replaced by a local
+    memory-bound stand-in on the comm stream (a ring all-reduce moves 2 (world-1)/world of the bucket in and out of HBM: here
+    one read-modify-write of the bucket against a scratch copy).  It measures what the fifth stream costs the step on ONE GPU
+    -- queue sharing, CU and HBM contention -- not the xGMI transfer time; gradients are left unchanged in value (x + 0)."""
+
+    def __init__(self, flat_grad: torch.Tensor, world: int = 8, bucket_mb: float = 32.0):
+        super().__init__(flat_grad, None, bucket_mb)
+        self.world = world
+        self.scratch = torch.zeros(self.bucket_numel, dtype=flat_grad.dtype, device=flat_grad.device)
+
+    def reduce(self, ranges, producers=None):
+        ranges = split_ranges(merge_ranges(ranges), self.bucket_numel)
+        self.reduced += ranges
+        evs = []
+        for s in (producers or [torch.cuda.current_stream(self.g.device)]):
+            ev = torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        with torch.cuda.stream(self.comm_stream):
+            for ev in evs:
+                self.comm_stream.wait_event(ev)
+            for off, n in ranges:
+                self.g[off:off + n].add_(self.scratch[:n])
+
+    def finish(self) -> float:
+        torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
+        return 1.0
 
 
 def shard_indices(num_items: int, rank: int, world: int, epoch_seed: int, shuffle: bool = True,

@@ -161,7 +161,10 @@ class Engine:
         # the stems' BatchNorm -> ReLU -> MaxPool as one forward pass and a two-pass backward (sfk_bn_maxpool_*)
         self.fuse_stem_tail = (os.environ.get("SFK_STEM_TAIL", "1") != "0" and hasattr(self.be, "bn_maxpool_fwd")
                                and self.be.bn_maxpool_supported(3, 2, 1))
-        self.tail_r_lane = os.environ.get("SFK_TAIL_RLANE", "0") == "1"    # R = dz^T a beside the first dgrad pass (_tail_bwd)
+        # R = dz^T a beside the first dgrad pass (_tail_bwd): 0 = on the pathway's lane (default), 2 = on its filter-gradient lane
+        # (neutral), 4 = on lanes of its own (an experiment: 948 clips/s with the default 4 hardware queues, 719 with 8)
+        self.tail_r_lane = int(os.environ.get("SFK_TAIL_RLANE", "0"))
+        assert self.tail_r_lane in (0, 2, 4)
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -727,7 +730,7 @@ class Engine:
         # it only before the small algebra that needs it.  Measured: see DESIGN.md section 4b (the lane carries a backlog of
         # earlier filter gradients; lanes of its own exceed the 4 hardware queues a process gets and serialise).
         home = pl.bwd.cur_lane
-        rl = home + 2 if (self.wgrad_lanes and self.tail_r_lane) else home
+        rl = home + self.tail_r_lane if (self.wgrad_lanes and self.tail_r_lane) else home
         if rl != home:
             pl.bwd.sync(rl, home)
             pl.bwd.cur_lane = rl
@@ -1061,7 +1064,7 @@ class Engine:
     _plan_serial = 0
     # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway.  Not more: a process gets
     # 4 hardware queues (GPU_MAX_HW_QUEUES), streams beyond that share one and serialise (6 lanes: 948 vs 1033 clips/s)
-    NLANES = 4
+    NLANES = 6 if os.environ.get("SFK_TAIL_RLANE", "0") == "4" else 4
 
     def lane_streams(self):
         """torch streams the schedule's lanes run on (one entry when the schedule is single-stream / on the CPU)"""
