@@ -171,10 +171,18 @@ typedef struct {
    * it avoids re-adding every tile through fp32 atomics (~1.3 TB/s chip-wide).  NULL / too small: atomics. */
   float* workspace;
   int64_t workspace_bytes;
+  /* optional FUSED DATA GRADIENT of the same dY (dg_w == NULL: off): dg_y[pixel][ci] = sum_co dY[pixel][co] * dg_w[ci][co],
+   * dg_w a [cin][cout] matrix in the maps' dtype, dg_y a map of x's extents with cin channels (written, not accumulated).
+   * For the fused block tail (sfk_bn_tail_*): R = dz^T a and the first data-gradient pass dz (A W)^T read dz ONCE -- the waves
+   * of the filter-gradient tile whose columns lie past taps x cin compute it from the dY rows already staged in LDS.
+   * Only where sfk_conv_wgrad_dg_supported(d) != 0 (bf16, pointwise, cout = 256, cin = 64). */
+  const void* dg_w;
+  sfk_fmap dg_y;
 } sfk_wgrad_desc;
 
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
 int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d); /* host-side query; <0 on error */
+int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d);        /* the fused data gradient (dg_w / dg_y) can run */
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_stem_conv_fwd / sfk_stem_conv_wgrad -- the stem Conv3d (kt,7,7) stride (1,2,2) padding (kt/2,3,3), bias=False
@@ -426,7 +434,8 @@ typedef struct {
   int32_t wgrad_target_8w;    /* 384:  resident-workgroup target of the 8-wave filter-gradient tile               */
   int32_t wgrad_target_4w;    /* 512:  ... of the 4-wave tile                                                     */
   int32_t wgrad_use_workspace;/* 1:    use sfk_wgrad_desc.workspace when given                                    */
-  int32_t wgrad_wide_co;      /* 1:    one 256 x 64 tile for wide-output / narrow-input layers                    */
+  int32_t wgrad_wide_co;      /* 3:    bit 0: one 256 x 64 tile for wide-output / narrow-input layers; bit 1: the LDS-DMA
+                                         256 x 128 tile (half idle) when cout = 256 and taps x cin = 64                  */
   int32_t bn_parts;           /* 1024: partial rows of the BatchNorm reductions (one resident generation)         */
   int32_t nt_apply_mb;        /* 0:    non-temporal loads+stores in sfk_bn_apply for maps >= this many MB (-1 off) */
   int32_t nt_reduce_mb;       /* 48:   non-temporal loads in sfk_bn_bwd_reduce                                    */

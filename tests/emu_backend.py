@@ -196,7 +196,14 @@ class EmuBackend:
             dw = p.dw[: p.cout * p.wtaps * p.cin].view(p.cout, p.wtaps, p.cin)
             for tap in p.taps:
                 dw[:, tap[3], :] += torch.einsum("nthwo,nthwc->oc", dY, _gather(X, rows, p.gs, tap))
+            if p.dg_w is not None:          # fused data gradient of the same dY (include/sfk.h sfk_wgrad_desc.dg_w / dg_y)
+                Wd = p.dg_w[: p.cin * p.cout].view(p.cin, p.cout).float()
+                p.dg_y.view5().copy_((dY @ Wd.t()).to(p.dg_y.dtype))
         return run
+
+    def conv_wgrad_dg_supported(self, p: WgradPass) -> bool:
+        return (p.dg_w is not None and p.x.dtype == torch.bfloat16 and p.cout == 256 and p.cin == 64 and len(p.taps) == 1
+                and tuple(p.taps[0][:3]) == (0, 0, 0) and tuple(p.gs) == (1, 1, 1))
 
     @staticmethod
     def _stem_x(p: StemSrc, dtype):

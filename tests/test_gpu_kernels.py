@@ -838,3 +838,40 @@ def test_conv_masked_store_with_dz_sums_bf16(hip):
         assert rel_err(pg.sum(0)[:, 0].cpu(), pc.sum(0)[:, 0]) < 2e-3 and float(pg[:, :, 1].abs().max()) == 0.0
         assert rel_err(pg.sum(0)[:, 0].cpu(), xg.float().cpu().view(-1, cout).sum(0)) < 1e-3     # sums of what was stored
 
+
+
+@pytest.mark.parametrize("dims", [(2, 3, 13, 11), (1, 2, 56, 56), (1, 1, 3, 3)], ids=str)
+def test_filter_gradient_with_fused_data_gradient_bf16(hip, dims):
+    """sfk_wgrad_desc.dg_w / dg_y: R = dY^T X (256 x 64) and the data gradient dY dg_w^T from ONE pass over dY -- the idle column
+    waves of the LDS-DMA filter-gradient tile; both results against the CPU restatement, with atomics and with the workspace"""
+    n, t, h, w = dims
+    cin, cout = 64, 256
+    gen = torch.Generator().manual_seed(sum(dims))
+    emu = EmuBackend()
+    dtype = torch.bfloat16
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=0)
+    dyc, dyg = fmap_pair(n, cout, t, h, w, dtype, gen)
+    wd = mk((cin * cout,), dtype, gen, scale=cout ** -0.5)
+    res = []
+    for be, x, dy, dev, use_ws in ((emu, xc, dyc, "cpu", False), (hip, xg, dyg, DEV, False), (hip, xg, dyg, DEV, True)):
+        dw = torch.ones(cout * cin, device=dev)                      # accumulated into
+        out = FMap(torch.full((n * t * h * w * (cin + 8),), 5.0, dtype=dtype, device=dev), n, t, h, w, cin, cin + 8, 8)
+        p = WgradPass(x, dy, (1, 1, 1), [(0, 0, 0, 0)], dw, 1, cin, cout, dg_w=wd.to(dev), dg_y=out)
+        assert be.conv_wgrad_dg_supported(p)
+        if use_ws:
+            p.workspace = torch.zeros(be.conv_wgrad_workspace_bytes(p) // 4 + 4, device=dev)
+        be.conv_wgrad(p)(stream() if dev != "cpu" else 0)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append((dw.cpu(), out.buf.float().cpu()))
+    for dwg, og in res[1:]:
+        assert rel_err(dwg - 1.0, res[0][0] - 1.0) < 2e-3
+        assert rel_err(og, res[0][1]) < TOL[dtype]
+        assert torch.equal(og.view(-1, cin + 8)[:, :8], res[0][1].view(-1, cin + 8)[:, :8])      # the neighbouring slice is untouched
+    # other shapes are announced as unsupported, and a descriptor that asks for the fusion there is refused
+    x2c, x2g = fmap_pair(n, 32, t, h, w, dtype, gen)
+    p = WgradPass(x2g, dyg, (1, 1, 1), [(0, 0, 0, 0)], torch.zeros(cout * 32, device=DEV), 1, 32, cout,
+                  dg_w=wd.to(DEV), dg_y=FMap(torch.zeros(n * t * h * w * 32, dtype=dtype, device=DEV), n, t, h, w, 32))
+    assert not hip.conv_wgrad_dg_supported(p)
+    with pytest.raises(Exception):
+        hip.conv_wgrad(p)(stream())

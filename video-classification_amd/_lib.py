@@ -127,6 +127,8 @@ class WgradPass:
     cin: int
     cout: int
     workspace: Optional[torch.Tensor] = None   # fp32 scratch for the partial-tile path (sfk_conv_wgrad_workspace_bytes)
+    dg_w: Optional[torch.Tensor] = None        # fused data gradient of the same dY: [cin][cout] matrix (include/sfk.h)
+    dg_y: Optional[FMap] = None                # ... its output map (cin channels)
 
 
 @dataclass
@@ -176,7 +178,8 @@ class _ConvDesc(C.Structure):
 class _WgradDesc(C.Structure):
     _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("dg_w", C.c_void_p), ("dg_y", _FMap)]
 
 
 class _StemSrc(C.Structure):
@@ -218,6 +221,7 @@ SIGNATURES = {
     "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
+    "sfk_conv_wgrad_dg_supported": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
     "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
     "sfk_stem_conv_fwd": [C.POINTER(_StemSrc), _PV, _P_FMAP, _PF, _PV],
@@ -409,7 +413,13 @@ class HipBackend:
         d.gs = (C.c_int32 * 3)(*p.gs)
         d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)
         d.dw, d.wtaps, d.cin, d.cout = p.dw.data_ptr(), p.wtaps, p.cin, p.cout
+        if p.dg_w is not None:
+            d.dg_w, d.dg_y = p.dg_w.data_ptr(), _c_fmap(p.dg_y)
         return d
+
+    def conv_wgrad_dg_supported(self, p: WgradPass) -> bool:
+        """the fused data gradient (p.dg_w, p.dg_y) can run with this filter-gradient pass"""
+        return p.dg_w is not None and bool(self.lib.sfk_conv_wgrad_dg_supported(C.byref(self._wgrad_desc(p))))
 
     def conv_wgrad_workspace_bytes(self, p: WgradPass) -> int:
         """bytes of scratch with which sfk_conv_wgrad sums its pixel splits without atomics (deterministically)"""

@@ -30,6 +30,9 @@ struct WgradK {
   uint32_t xbytes, dbytes;        // extents of the buffer resources
   float4* ws;                     // partial-tile workspace (NULL: fp32 atomics straight into dw)
   int ntiles;                     // cotiles * citiles
+  const void* dgw;                // fused data gradient (DG kernels): [cin][cout] matrix, output map
+  void* dgy;
+  int dgld, dgoff;
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -275,7 +278,17 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
 
-template <int TCO, int NW>
+__device__ __forceinline__ void wg_swap16f(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+// DG (TCO = 256, 8 waves, taps x cin = 64): the four waves of the second column half have no filter-gradient columns; they
+// compute the data gradient  dg_y[pixel][ci] = sum_co dY[pixel][co] dg_w[ci][co]  of the stage's 32 pixels from the dY rows
+// the ring already holds -- dY is read from HBM once for both gradients.  Wave d of those four: pixels 16 (d & 1) .. +15,
+// channels 32 (d >> 1) .. +31; its 16 filter fragments (2 x 8 K-steps of 32 co) live in registers for the whole kernel.
+template <int TCO, int NW, bool DG = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_kernel(const WgradK k) {
   constexpr int TCI = 128, R = MK;
   constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
@@ -371,6 +384,70 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xs + (wave * NDI + j) * 1024), 16, (int)xvo[j], xso, 0, 0);
   };
 
+  // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
+  // (see conv_igemm.hip ring_wait)
+  auto ring_wait = [&]() {
+    static_assert(NDO + NDI >= 2 && NDO + NDI <= 4, "DMA count");
+    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  if constexpr (DG) {
+    static_assert(TCO == 256 && NW == 8, "fused data gradient: the 256-channel tile");
+    if (wci == 1) {
+      const int l15 = lane & 15, g4 = lane >> 4;
+      const int pf = wco & 1, cp = wco >> 1;
+      const bf16_t* wp = static_cast<const bf16_t*>(k.dgw);
+      bf16x8 wdf[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          wdf[i][ks] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)(32 * cp + 16 * i + l15) * k.cout + 32 * ks + 8 * g4);
+      const int prow = 16 * pf + l15, psw = wg_swz(prow);
+      bf16_t* yp = static_cast<bf16_t*>(k.dgy);
+      auto dgc = [&](int slot_base, int st) __attribute__((always_inline)) {
+        f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + slot_base + prow * LO + (((4 * ks + g4) ^ psw) << 4));
+          da[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdf[0][ks], b, da[0], 0, 0, 0);
+          da[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdf[1][ks], b, da[1], 0, 0, 0);
+        }
+        // rows = channels 4 g + r of fragment i, column = pixel l15: pair the fragments -> 8 consecutive channels per lane
+        float v[8] = {da[0][0], da[0][1], da[0][2], da[0][3], da[1][0], da[1][1], da[1][2], da[1][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wg_swap16f(v[e], v[4 + e]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        const int m = st * R + prow;
+        if (m < k.M)
+          *reinterpret_cast<bf16x8*>(yp + (int64_t)m * k.dgld + k.dgoff + 32 * cp + 16 * (g4 & 1) + 8 * (g4 >> 1)) = o;
+      };
+      dma(stage0, 0);
+      dma(stage0 + 1, 1);
+      ring_wait();
+      for (int st = stage0;;) {
+        dma(st + 2, 2); dgc(0 * BUF, st); ring_wait();
+        if (++st >= stage1) break;
+        dma(st + 2, 0); dgc(1 * BUF, st); ring_wait();
+        if (++st >= stage1) break;
+        dma(st + 2, 1); dgc(2 * BUF, st); ring_wait();
+        if (++st >= stage1) break;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (k.ws) {                                       // this wave's (unused) partial-tile slots: zeros for the ordered reduce
+        float4* wsp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wsp[i * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+  }
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -419,16 +496,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
-  // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
-  // (see conv_igemm.hip ring_wait)
-  auto ring_wait = [&]() {
-    static_assert(NDO + NDI >= 2 && NDO + NDI <= 4, "DMA count");
-    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-
   dma(stage0, 0);
   dma(stage0 + 1, 1);
   ring_wait();
@@ -526,7 +593,7 @@ int launch_reduce(const WgradK& k, int splits, hipStream_t s) {
   return SFK_OK;
 }
 
-template <int TCO, int NW>
+template <int TCO, int NW, bool DG = false>
 int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
@@ -546,10 +613,22 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   k.ntiles = base;
   if (dry) { *dry = (int64_t)splits * base * NW * 16 * 64 * 16; return SFK_OK; }
   if (k.ws && (int64_t)splits * base * NW * 16 * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<NW, TCO / 64, 4, 4>(k, splits, s);
   return SFK_OK;
+}
+
+// the fused data gradient rides on the 256 x 128 LDS-DMA tile with taps x cin = 64 (its second column half is idle)
+bool dg_ok(const sfk_wgrad_desc* d) {
+  if (!d->dg_w || d->x.dtype != SFK_BF16 || d->cout != 256 || d->cin != 64 || d->ntaps != 1) return false;
+  if (d->taps[0].dt || d->taps[0].dh || d->taps[0].dw || d->gs[0] != 1 || d->gs[1] != 1 || d->gs[2] != 1) return false;
+  if (d->x.t != d->dy.t || d->x.h != d->dy.h || d->x.w != d->dy.w) return false;
+  const sfk_fmap* y = &d->dg_y;
+  if (!sfk_fmap_ok(y) || y->dtype != SFK_BF16 || y->c != d->cin || y->n != d->x.n || y->t != d->x.t || y->h != d->x.h ||
+      y->w != d->x.w || (y->ld % 8) || (y->c_off % 8) || (((uintptr_t)y->ptr) & 15) || (((uintptr_t)d->dg_w) & 15))
+    return false;
+  return sfk_fmap_bytes(&d->x) < 0x7FF00000ll && sfk_fmap_bytes(&d->dy) < 0x7FF00000ll;
 }
 
 int validate(const sfk_wgrad_desc* d) {
@@ -611,6 +690,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   for (int i = 0; i < SFK_MAX_TAPS; ++i) k.taps[i] = d->taps[i < d->ntaps ? i : 0];
   const int use_ws = sfk_tune().wgrad_use_workspace;
   k.ws = use_ws ? reinterpret_cast<float4*>(d->workspace) : nullptr;
+  k.dgw = nullptr; k.dgy = nullptr; k.dgld = 0; k.dgoff = 0;
   const int cols = d->ntaps * d->cin;
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
@@ -620,6 +700,14 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   if constexpr (sizeof(T) == 2) {
     // wide output, narrow input (slow res2 conv_c: 64 -> 256): ONE tile holds all of dW, so x and dY are each read once
     const int wide_co = sfk_tune().wgrad_wide_co;
+    if (d->dg_w) {                                      // fused data gradient: only on the tile below
+      if (!dg_ok(d)) return SFK_ERR_UNSUPPORTED;
+      k.dgw = d->dg_w; k.dgy = d->dg_y.ptr; k.dgld = d->dg_y.ld; k.dgoff = d->dg_y.c_off;
+      return launch_dma<256, 8, true>(k, d, s, dry);
+    }
+    if ((wide_co & 2) && d->cout == 256 && cols == 64 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u)
+      return launch_dma<256, 8>(k, d, s, dry);   // the LDS-DMA tile with its second column half idle still beats the
+                                                 // register-staged 256 x 64 tile: 102..108 vs 133..136 us on slow res2's R
     if (wide_co && d->cout >= 256 && cols > 32 && cols <= 64) return launch_cfg<T, 256, 64, 1>(k, d, s, dry);
   }
   if (cols <= 32) {
@@ -640,6 +728,10 @@ extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
   int64_t bytes = 0;
   const int r = d->x.dtype == SFK_BF16 ? launch<bf16_t>(d, nullptr, &bytes) : launch<float>(d, nullptr, &bytes);
   return r != SFK_OK ? r : bytes;
+}
+
+extern "C" int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d) {
+  return (d && validate(d) == SFK_OK && dg_ok(d)) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream) {

@@ -163,6 +163,7 @@ class Engine:
                                and self.be.bn_maxpool_supported(3, 2, 1))
         # R = dz^T a beside the first dgrad pass (_tail_bwd): 0 = on the pathway's lane (default), 2 = on its filter-gradient lane
         # (neutral), 4 = on lanes of its own (an experiment: 948 clips/s with the default 4 hardware queues, 719 with 8)
+        self.fuse_tail_dg = os.environ.get("SFK_TAIL_DG", "1") != "0"      # R and the first dgrad pass in one kernel (_tail_bwd)
         self.tail_r_lane = int(os.environ.get("SFK_TAIL_RLANE", "0"))
         assert self.tail_r_lane in (0, 2, 4)
         self._side = None
@@ -729,8 +730,17 @@ class Engine:
         # needs no gradient statistics): tail_r_lane puts it on the pathway's filter-gradient lane and the pathway waits for
         # it only before the small algebra that needs it.  Measured: see DESIGN.md section 4b (the lane carries a backlog of
         # earlier filter gradients; lanes of its own exceed the 4 hardware queues a process gets and serialise).
+        # ... and where the filter-gradient tile has idle waves (slow res2: 256 x 64) those compute that first pass from the dz
+        # rows the tile already holds: dz is read ONCE for R and dz (A W) (sfk_wgrad_desc.dg_w / dg_y)
+        rows = (d_out.t, d_out.h, d_out.w)
+        wp.dg_w, wp.dg_y = tail["wd"], dab
+        fused_dg = self.fuse_tail_dg and hasattr(self.be, "conv_wgrad_dg_supported") and self.be.conv_wgrad_dg_supported(wp)
+        if fused_dg:
+            meta = dict(meta, flops=2.0 * meta["flops"], bytes=meta["bytes"] + float(esz * d_out.pixels * c4))
+        else:
+            wp.dg_w = wp.dg_y = None
         home = pl.bwd.cur_lane
-        rl = home + self.tail_r_lane if (self.wgrad_lanes and self.tail_r_lane) else home
+        rl = home + self.tail_r_lane if (self.wgrad_lanes and self.tail_r_lane and not fused_dg) else home
         if rl != home:
             pl.bwd.sync(rl, home)
             pl.bwd.cur_lane = rl
@@ -739,10 +749,10 @@ class Engine:
         else:
             pl.bwd.append(self.be.conv_wgrad(wp), **meta)
         pl.bwd.cur_lane = home
-        rows = (d_out.t, d_out.h, d_out.w)
-        pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, tail["wd"], 1, C, c4)),
-                      kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
-                      bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
+        if not fused_dg:
+            pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, tail["wd"], 1, C, c4)),
+                          kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
+                          bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
         if rl != home:
             pl.bwd.sync(home, rl)
         ws = self._buf(f"tailWs.{tag}", C * c4)
