@@ -288,8 +288,7 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
  *   A needs the forward statistics only, so pass 1 does not wait for R: it runs beside the R filter-gradient call.
  *   w = the conv's filter [cout][c] in compute precision (w_dtype).
  * sfk_bn_tail_bwd: dgamma += , dbeta += , dw += (fp32 [cout][c]), and the operands of the second data-gradient pass
- *     ws [cout][c] (w_dtype) = diag(B) W    -> m32 = sfk_conv_wgrad(x = W as a [cout pixels][c] map, dy = ws) = W^T diag(B) W;
- *                                              cast to w_dtype -> pass 2: da += a . m + bias   (accumulate + ep.shift)
+ *     m [c][c] (w_dtype) = W^T diag(B) W   -> pass 2: da += a . m + bias   (sfk_conv_igemm, accumulate + ep.shift)
  *     bias [c] fp32 = C W
  */
 int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
@@ -298,7 +297,7 @@ int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, in
                     float* shift, float* t, void* wd, sfk_stream_t stream);
 int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, const float* gram, const float* t,
                     int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma,
-                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* ws,
+                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* m,
                     float* bias, float* coef, sfk_stream_t stream);
 /* r [cout][c]; dz_partials [nparts][cout][2], component 0 = partial sums of dz as the kernel that WROTE dz left them
  * (sfk_bn_bwd_reduce with y == NULL, or the data-gradient pass with bnb.y_bn.ptr == NULL + out_relu_bits); coef: [cout][4]

@@ -166,7 +166,7 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws,
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
                     bias, coef):
         def run(stream):
             R = r[: cout * c].view(cout, c).double()
@@ -184,7 +184,7 @@ class EmuBackend:
             B = -A * c2 * is_
             Cc = A * (c2 * is_ * mu - c1)
             dw[: cout * c].add_((A[:, None] * R + B[:, None] * T + Cc[:, None] * g[None, :]).float().reshape(-1))
-            ws[: cout * c].copy_((B[:, None] * W).reshape(-1).to(ws.dtype))
+            m[: c * c].copy_((W.t() @ (B[:, None] * W)).reshape(-1).to(m.dtype))
             bias[:c].copy_((Cc @ W).float())
         return run
 

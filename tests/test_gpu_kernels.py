@@ -702,7 +702,7 @@ def test_bottleneck_tail_forward_backward(hip, dtype, shape):
     got = run_tail(hip, DEV, dtype, *case, stream=stream())
     emu = run_tail(EmuBackend(), "cpu", dtype, *case)
     tol = 2e-5 if dtype == torch.float32 else 1.6e-2
-    for k in ("out", "mean", "var", "rm", "rv", "dz", "dW", "dgamma", "dbeta", "da", "m32", "bias"):
+    for k in ("out", "mean", "var", "rm", "rv", "dz", "dW", "dgamma", "dbeta", "da", "m", "bias"):
         assert rel_err(got[k], emu[k]) < (tol if k not in ("var", "rv") else 10 * tol), (k, rel_err(got[k], emu[k]))
     assert got["nbt"] == 1
     if dtype == torch.float32:

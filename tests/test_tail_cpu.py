@@ -71,12 +71,8 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     r = f32(cout * c)
     be.conv_wgrad(WgradPass(av, dz, ONE, TAP0, r, 1, c, cout))(stream)
     dgamma, dbeta, dw, bias, coef = f32(cout), f32(cout), f32(cout * c), f32(c), f32(cout * 4)
-    ws = torch.zeros(cout * c, dtype=dtype, device=dev)
-    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, ws, bias, coef)(stream)
-    m32 = f32(c * c)
-    wmap = FMap(wq, 1, 1, 1, cout, c)                                  # the filter as a [cout pixels][c] map
-    be.conv_wgrad(WgradPass(wmap, FMap(ws, 1, 1, 1, cout, c), ONE, TAP0, m32, 1, c, c))(stream)
-    m = m32.to(dtype)
+    m = torch.zeros(c * c, dtype=dtype, device=dev)
+    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, m, bias, coef)(stream)
     da = FMap(torch.zeros(n * t * h * w * c, dtype=dtype, device=dev), n, t, h, w, c)
     be.conv_igemm(ConvPass(dz, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, wd, 1, cout, c))(stream)
     be.conv_igemm(ConvPass(av, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, m, 1, c, c, accumulate=True,
@@ -86,7 +82,7 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     cpu = lambda x: x.float().cpu()
     return dict(out=cpu(out.view5()), mean=cpu(mean), var=cpu(1.0 / invstd ** 2 - eps), rm=cpu(rm), rv=cpu(rv), nbt=int(nbt[0]),
                 da=cpu(da.view5()), dW=cpu(dw).view(cout, c), dgamma=cpu(dgamma), dbeta=cpu(dbeta), dz=cpu(dz.view5()),
-                m32=cpu(m32), bias=cpu(bias))
+                m=cpu(m), bias=cpu(bias))
 
 
 def make_case(n, t, h, w, c, cout, seed=0, mean_shift=0.0):

@@ -565,12 +565,13 @@ class HipBackend:
                            momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
                            _ptr(scale), _ptr(shift), _ptr(t), _ptr(wd), keep=ts)
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws,
+    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
                     bias, coef):
-        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef)
+        """m: [c][c] filter (compute precision) of the second data-gradient pass, W^T diag(B) W (include/sfk.h)"""
+        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef)
         return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(gram), _ptr(t), c, gld, _ptr(w),
                            _DT[w.dtype], cout, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
-                           _ptr(ws), _ptr(bias), _ptr(coef), keep=ts)
+                           _ptr(m), _ptr(bias), _ptr(coef), keep=ts)
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

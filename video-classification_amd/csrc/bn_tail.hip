@@ -9,7 +9,7 @@
 //               wd = (diag(A) W)^T, A = gamma * invstd: the filter of the backward's FIRST data-gradient pass dz (A W) is
 //               known once the statistics are, so that pass can run beside R = dz^T a instead of behind it
 //     backward: dgamma, dbeta, dW = diag(A) R + diag(B) T + C (x) g, and the operands of the second data-gradient pass
-//               ws = diag(B) W (its Gram-like product W^T ws is one more sfk_conv_wgrad call), bias = C W
+//               m = W^T diag(B) W (c x c, in the filter's precision), bias = C W
 // Sums over channels / rows run in double and in a fixed order: deterministic, no atomics.
 #include "sfk_common.h"
 
@@ -152,12 +152,12 @@ __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restri
   coef[co * 4 + 3] = 0.f;
 }
 
-// 32 x 32 (co, ci) tiles: dW += A R + B T + C g;  ws = B W
+// 32 x 32 (co, ci) tiles: dW += A R + B T + C g
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restrict__ rx, const float* __restrict__ gram,
-                                                            const float* __restrict__ t, int c, int gld, const void* w,
-                                                            int cout, const float* __restrict__ coef, float* dw, D* ws) {
-  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+__device__ __forceinline__ void bn_tail_apply_part(int bx, int by, const float* __restrict__ rx, const float* __restrict__ gram,
+                                                   const float* __restrict__ t, int c, int gld, int cout,
+                                                   const float* __restrict__ coef, float* dw) {
+  const int co0 = by * 32, ci0 = bx * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -166,18 +166,40 @@ __global__ __launch_bounds__(256) void bn_tail_apply_kernel(const float* __restr
       const float A = coef[co * 4], B = coef[co * 4 + 1], Cc = coef[co * 4 + 2];
       const int64_t idx = (int64_t)co * c + ci;
       dw[idx] += A * rx[idx] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
-      ws[idx] = (D)(B * wload<D>(w, idx));
     }
   }
 }
 
+// m[i][j] = sum_co B[co] W[co][i] W[co][j]  (c x c, symmetric): 16 x 16 outputs per block, one per thread; the co axis is
+// walked in order through LDS slabs of 16 output channels (fixed summation order)
+template <typename D>
+__device__ __forceinline__ void bn_tail_m_part(int bx, int by, const void* w, int c, int cout, const float* __restrict__ coef, D* m) {
+  __shared__ float wi[16][17], wj[16][17], bco[16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i = by * 16 + ty, j = bx * 16 + tx;
+  float acc = 0.f;
+  for (int co0 = 0; co0 < cout; co0 += 16) {
+    // stage 16 output channels x (16 i-columns, 16 j-columns) of W and their B
+    const int co = co0 + ty;
+    const int ci = by * 16 + tx, cj = bx * 16 + tx;
+    wi[ty][tx] = (co < cout && ci < c) ? wload<D>(w, (int64_t)co * c + ci) : 0.f;
+    wj[ty][tx] = (co < cout && cj < c) ? wload<D>(w, (int64_t)co * c + cj) : 0.f;
+    if (threadIdx.x < 16) bco[threadIdx.x] = co0 + threadIdx.x < cout ? coef[(co0 + threadIdx.x) * 4 + 1] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += bco[q] * wi[q][ty] * wj[q][tx];
+    __syncthreads();
+  }
+  if (i < c && j < c) m[(int64_t)i * c + j] = (D)acc;
+}
+
 // bias[ci] = sum_co C[co] W[co][ci]: 16 columns x 16 row partitions per block, fixed summation order
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_bias_kernel(const void* w, int c, int cout, const float* __restrict__ coef,
-                                                           float* bias) {
+__device__ __forceinline__ void bn_tail_bias_part(int bx, const void* w, int c, int cout, const float* __restrict__ coef,
+                                                  float* bias) {
   __shared__ double red[16][17];
   const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int ci = blockIdx.x * 16 + col;
+  const int ci = bx * 16 + col;
   double s = 0.0;
   if (ci < c) {
 #pragma unroll 4
@@ -191,6 +213,18 @@ __global__ __launch_bounds__(256) void bn_tail_bias_kernel(const void* w, int c,
     for (int p = 0; p < 16; ++p) a += red[p][col];
     bias[ci] = (float)a;
   }
+}
+
+// ONE launch for everything that only needs the coefficients: block ranges [dW tiles | m tiles | bias columns]
+template <typename D>
+__global__ __launch_bounds__(256) void bn_tail_post_kernel(const float* rx, const float* gram, const float* t, int c, int gld,
+                                                           const void* w, int cout, const float* coef, float* dw, D* m,
+                                                           float* bias, int ax, int nap, int mx, int nm) {
+  int b = blockIdx.x;
+  if (b < nap) { bn_tail_apply_part<D>(b % ax, b / ax, rx, gram, t, c, gld, cout, coef, dw); return; }
+  b -= nap;
+  if (b < nm) { bn_tail_m_part<D>(b % mx, b / mx, w, c, cout, coef, m); return; }
+  bn_tail_bias_part<D>(b - nm, w, c, cout, coef, bias);
 }
 
 inline bool tail_args_ok(int c, int gld, int cout, int dtype) {
@@ -221,25 +255,25 @@ extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const 
 template <typename D>
 static int tail_bwd_launch(const float* rx, const float* parts, int nparts, const float* gram, const float* t, int c, int gld, const void* w, int cout,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                           float* dw, void* ws, float* bias, float* coef, hipStream_t s) {
+                           float* dw, void* m, float* bias, float* coef, hipStream_t s) {
   hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, parts, nparts, gram, c, gld, w, cout, gamma, mean,
                      invstd, dgamma, dbeta, coef);
-  hipLaunchKernelGGL(bn_tail_apply_kernel<D>, dim3((c + 31) / 32, (cout + 31) / 32), dim3(256), 0, s, rx, gram, t, c, gld,
-                     w, cout, coef, dw, static_cast<D*>(ws));
-  hipLaunchKernelGGL(bn_tail_bias_kernel<D>, dim3((c + 15) / 16), dim3(256), 0, s, w, c, cout, coef, bias);
+  const int ax = (c + 31) / 32, ay = (cout + 31) / 32, mx = (c + 15) / 16, nb = (c + 15) / 16;
+  hipLaunchKernelGGL(bn_tail_post_kernel<D>, dim3(ax * ay + mx * mx + nb), dim3(256), 0, s, rx, gram, t, c, gld, w, cout, coef, dw,
+                     static_cast<D*>(m), bias, ax, ax * ay, mx, mx * mx);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
 
 extern "C" int sfk_bn_tail_bwd(const float* rx, const float* parts, int32_t nparts, const float* gram, const float* t,
                                int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
-                               float* dgamma, float* dbeta, float* dw, void* ws, float* bias, float* coef,
+                               float* dgamma, float* dbeta, float* dw, void* m, float* bias, float* coef,
                                sfk_stream_t stream) {
-  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !ws || !bias || !coef)
+  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !m || !bias || !coef)
     return SFK_ERR_INVALID;
   if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return w_dtype == SFK_BF16
-             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef, s)
-             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, ws, bias, coef, s);
+             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s)
+             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s);
 }

@@ -705,7 +705,7 @@ class Engine:
                     if self._tail_ok(Lc):
                         c4, C = Lc.eg.cin, Lc.eg.cout
                         nf += round_up((c4 + V) ** 2, 64)
-                        nb += round_up(C * c4, 64) + round_up(c4 * c4, 64)
+                        nb += round_up(C * c4, 64)
         self._tailz = {"f": self._buf("tailz.f", nf, torch.float32)[:nf] if (train and nf) else None,
                        "b": self._buf("tailz.b", nb, torch.float32)[:nb] if (train and nb) else None}
         self._tailz_off = {"f": 0, "b": 0}
@@ -755,23 +755,14 @@ class Engine:
                           bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
         if rl != home:
             pl.bwd.sync(home, rl)
-        ws = self._buf(f"tailWs.{tag}", C * c4)
         bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
         coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
+        m = self._buf(f"tailM.{tag}", c4 * c4)             # W^T diag(B) W, the filter of the second data-gradient pass
         pl.bwd.append(self.be.bn_tail_bwd(r, dz_parts[0], dz_parts[1], tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
                                           tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
-                                          self._gslice(Lc.w_off, Lc.w_numel), ws, bias, coef))
+                                          self._gslice(Lc.w_off, Lc.w_numel), m, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
         pl.grad_marks.append((len(pl.bwd), (Lc.w_off, round_up(Lc.w_numel, self.vec))))
-        # m = W^T diag(B) W: one more filter-gradient call, its "pixels" are conv_c's output channels
-        m32 = self._tail_zero("b", c4 * c4)
-        wmap, wsmap = FMap(w, 1, 1, 1, C, c4), FMap(ws, 1, 1, 1, C, c4)
-        pl.bwd.append(self.be.conv_wgrad(WgradPass(wmap, wsmap, (1, 1, 1), self.TAP0, m32, 1, c4, c4)))
-        if self.dtype == torch.float32:
-            m = m32
-        else:
-            m = self._buf(f"tailM.{tag}", c4 * c4)
-            pl.bwd.append(self.be.cast(m32, m, c4 * c4))
         pl.bwd.append(self.be.conv_igemm(ConvPass(ab, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, m, 1, c4, c4,
                                                   accumulate=True, ep=ConvEpilogue(shift=bias))),
                       kind="conv_dgrad", layer=Lc.cb.conv_key + ":m", cout=c4, flops=2.0 * d_out.pixels * c4 * c4,
