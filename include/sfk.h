@@ -433,8 +433,9 @@ typedef struct {
   int32_t wgrad_target_8w;    /* 384:  resident-workgroup target of the 8-wave filter-gradient tile               */
   int32_t wgrad_target_4w;    /* 512:  ... of the 4-wave tile                                                     */
   int32_t wgrad_use_workspace;/* 1:    use sfk_wgrad_desc.workspace when given                                    */
-  int32_t wgrad_wide_co;      /* 3:    bit 0: one 256 x 64 tile for wide-output / narrow-input layers; bit 1: the LDS-DMA
-                                         256 x 128 tile (half idle) when cout = 256 and taps x cin = 64                  */
+  int32_t wgrad_wide_co;      /* 7:    bit 0: one 256 x 64 tile for wide-output / narrow-input layers; bit 1: the LDS-DMA
+                                         256 x 128 tile (half idle) when cout = 256 and taps x cin = 64; bit 2: Gram
+                                         matrices (x and dy the same map) stage ONE tile for both operands              */
   int32_t bn_parts;           /* 1024: partial rows of the BatchNorm reductions (one resident generation)         */
   int32_t nt_apply_mb;        /* 0:    non-temporal loads+stores in sfk_bn_apply for maps >= this many MB (-1 off) */
   int32_t nt_reduce_mb;       /* 48:   non-temporal loads in sfk_bn_bwd_reduce                                    */

@@ -104,8 +104,11 @@ template <int TC> struct WT<float, TC> {
 // Block tile: TCO output channels x TCI columns of the flattened (tap, cin) axis; 4 waves as 2 x 2.  A stage is
 // KS K-steps (KS*32 pixels) between two barriers.  Column segments (16 B) are gathered independently, so a tile may
 // straddle taps and narrow layers put ALL their taps into one tile (9 x 8 channels = 72 columns).
-template <typename T, int TCO, int TCI, int KS>
+// GRAM (TCO == TCI, x and dy the SAME map, pointwise): one staged tile serves both operands -- half the loads and LDS stores
+// of the Gram matrix  G = a^T a  of the fused block tail (sfk_bn_tail_fwd).
+template <typename T, int TCO, int TCI, int KS, bool GRAM = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
+  static_assert(!GRAM || TCO == TCI, "Gram matrix: square tile");
   using WO = WT<T, TCO>;
   using WI = WT<T, TCI>;
   constexpr int VEC = WO::VEC;
@@ -173,8 +176,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
     const int m = stage * R + row;
     const bool mok = stage < k.nchunks && m < k.M;       // past the end: every slot OOB (zeros), keeps the body branch-free
     const uint32_t drow = (uint32_t)m * (uint32_t)(k.dld * (int)sizeof(T));
+    if constexpr (!GRAM) {
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) dr[i] = sfk_buffer_load16(drs, (mok && di_off[i] != SFK_OOB) ? drow + di_off[i] : SFK_OOB);
+      for (int i = 0; i < NLO; ++i) dr[i] = sfk_buffer_load16(drs, (mok && di_off[i] != SFK_OOB) ? drow + di_off[i] : SFK_OOB);
+    }
     if (linear) {   // pointwise stride-1 conv: the gathered pixel IS the row
       const uint32_t xrow = (uint32_t)m * (uint32_t)(k.xld * (int)sizeof(T));
 #pragma unroll
@@ -199,8 +204,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
   auto lstore = [&](int buf) {
     char* ds = smem + buf * BUF;
     char* xs = ds + TILEO;
+    if constexpr (!GRAM) {
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) *reinterpret_cast<uint4*>(ds + di_soff[i]) = dr[i];
+      for (int i = 0; i < NLO; ++i) *reinterpret_cast<uint4*>(ds + di_soff[i]) = dr[i];
+    }
 #pragma unroll
     for (int i = 0; i < NLI; ++i) *reinterpret_cast<uint4*>(xs + xi_soff[i]) = xr[i];
   };
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK k) {
       typename WO::frag a[FO];
       typename WI::frag b[FI];
 #pragma unroll
-      for (int i = 0; i < FO; ++i) a[i] = WO::load(ds + ks * MK * ROWO, wco * (TCO / 2) + 16 * i, lane);
+      for (int i = 0; i < FO; ++i) a[i] = WO::load((GRAM ? xs : ds) + ks * MK * ROWO, wco * (TCO / 2) + 16 * i, lane);
 #pragma unroll
       for (int j = 0; j < FI; ++j) b[j] = WI::load(xs + ks * MK * ROWI, wci * (TCI / 2) + 16 * j, lane);
 #pragma unroll
@@ -647,7 +654,7 @@ int validate(const sfk_wgrad_desc* d) {
   return SFK_OK;
 }
 
-template <typename T, int TCO, int TCI, int KS>
+template <typename T, int TCO, int TCI, int KS, bool GRAM = false>
 int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
@@ -667,7 +674,7 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   constexpr int FO = TCO / 32, FI = TCI / 32;
   if (dry) { *dry = (int64_t)splits * base * 4 * FO * FI * 64 * 16; return SFK_OK; }
   if (k.ws && (int64_t)splits * base * 4 * FO * FI * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TCO, TCI, KS, GRAM>), dim3((unsigned)(base * splits)), dim3(256), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<4, 2, FO, FI>(k, splits, s);
   return SFK_OK;
@@ -710,6 +717,12 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
                                                  // register-staged 256 x 64 tile: 102..108 vs 133..136 us on slow res2's R
     if (wide_co && d->cout >= 256 && cols > 32 && cols <= 64) return launch_cfg<T, 256, 64, 1>(k, d, s, dry);
   }
+  // Gram matrix (x and dy the same pointwise map, one tile): the tile is staged once for both operands
+  const bool gram = d->x.ptr == d->dy.ptr && d->x.ld == d->dy.ld && d->x.c_off == d->dy.c_off && d->cin == d->cout && d->ntaps == 1 &&
+                    d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 && d->gs[2] == 1 &&
+                    (sfk_tune().wgrad_wide_co & 4);
+  if (gram && cols <= 32) return launch_cfg<T, 32, 32, 4, true>(k, d, s, dry);
+  if (gram && cols > 64 && cols <= 128) return launch_cfg<T, 128, 128, 1, true>(k, d, s, dry);
   if (cols <= 32) {
     if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s, dry);
     if (d->cout <= 64) return launch_cfg<T, 64, 32, 4>(k, d, s, dry);
