@@ -430,8 +430,8 @@ typedef struct {
   int32_t igemm_short_k;      /* 5:    exact-count K loop for layers of <= this many K-steps                      */
   int32_t igemm_small_k;      /* 0:    128x128 instead of 256x128 tiles up to this K (cin * taps)                 */
   int32_t igemm_wide_store;   /* 1:    16-byte epilogue stores                                                    */
-  int32_t wgrad_target_8w;    /* 384:  resident-workgroup target of the 8-wave filter-gradient tile               */
-  int32_t wgrad_target_4w;    /* 512:  ... of the 4-wave tile                                                     */
+  int32_t wgrad_target_8w;    /* 192:  workgroup target (pixel splits x tiles) of the 8-wave filter-gradient tile  */
+  int32_t wgrad_target_4w;    /* 256:  ... of the 4-wave tile                                                     */
   int32_t wgrad_use_workspace;/* 1:    use sfk_wgrad_desc.workspace when given                                    */
   int32_t wgrad_wide_co;      /* 7:    bit 0: one 256 x 64 tile for wide-output / narrow-input layers; bit 1: the LDS-DMA
                                          256 x 128 tile (half idle) when cout = 256 and taps x cin = 64; bit 2: Gram
@@ -444,7 +444,7 @@ typedef struct {
   int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
   int32_t igemm_tile256;      /* 3:    bit 0: 256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs;
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
-  int32_t reserved;
+  int32_t wgrad_target_gen;   /* 768:  ... of the register-staged filter-gradient kernels (0 = 1024)               */
 } sfk_tuning;
 void sfk_default_tuning(sfk_tuning* out);
 int sfk_init(const sfk_tuning* t); /* NULL = defaults */

@@ -663,7 +663,8 @@ int launch_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   k.nchunks = (k.M + R - 1) / R;
   // pixel splits: enough workgroups to cover the 256 CUs several times, at least 4 stages each
   const int base = cotiles * k.citiles;
-  int splits = (1024 + base - 1) / base;
+  const int target = sfk_tune().wgrad_target_gen > 0 ? sfk_tune().wgrad_target_gen : 1024;
+  int splits = (target + base - 1) / base;
   const int max_splits = (k.nchunks + 3) / 4;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

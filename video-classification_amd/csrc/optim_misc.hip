@@ -202,13 +202,13 @@ extern "C" int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream) {
 
 // ------------------------------------------------------------------ tuning table (sfk_init)
 namespace {
-sfk_tuning g_tuning = {5, 0, 1, 384, 512, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 0};
+sfk_tuning g_tuning = {5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 768};
 bool g_tuning_set = false;
 }  // namespace
 const sfk_tuning& sfk_tune() { return g_tuning; }
 
 extern "C" void sfk_default_tuning(sfk_tuning* out) {
-  if (out) *out = sfk_tuning{5, 0, 1, 384, 512, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 0};
+  if (out) *out = sfk_tuning{5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 768};
 }
 
 extern "C" void sfk_get_tuning(sfk_tuning* out) {
