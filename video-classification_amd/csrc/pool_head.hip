@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* feat, const fl
   const float* fp = feat + (int64_t)ni * f;
   const float* wp = w + (int64_t)ki * f;
   float s = 0.f;
+#pragma unroll 8                                    // (the forward's last kernel: keep 16 loads in flight per lane)
   for (int i = lane; i < f; i += 64) s += fp[i] * wp[i];
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) s += __shfl_xor(s, sft);

@@ -977,8 +977,18 @@ class Engine:
         dfeat = self._buf("dfeat", n * F, torch.float32)
         if self._tailz["b"] is not None:
             pl.bwd.append(be.fill_zero(self._tailz["b"]))
-        pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, self._gslice(self.fc_w_off, F * K),
-                                self._gslice(self.fc_b_off, K), n, F, K))
+        # the Linear's data gradient starts the backward chain; its filter / bias gradient feeds nothing downstream and goes
+        # to the filter-gradient lane like every other one (16 us off the turn-around between forward and backward)
+        if self.wgrad_lanes:
+            pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, None, None, n, F, K))
+            pl.bwd.sync(2, 0)
+            pl.bwd.cur_lane = 2
+            pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, None, self._gslice(self.fc_w_off, F * K),
+                                    self._gslice(self.fc_b_off, K), n, F, K))
+            pl.bwd.cur_lane = 0
+        else:
+            pl.bwd.append(be.fc_bwd(pl.dlogits, feat, fcw, dfeat, self._gslice(self.fc_w_off, F * K),
+                                    self._gslice(self.fc_b_off, K), n, F, K))
         pl.grad_marks.append((len(pl.bwd), (self.fc_w_off, self.layers[0].g_off - self.fc_w_off)))
         d_xs = self._fmap("d.cat.4", n, xs_out.t, xs_out.h, xs_out.w, xs_out.c)
         pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
