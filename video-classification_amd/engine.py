@@ -950,19 +950,21 @@ class Engine:
             stage_recs.append(recs_sp)
             xs_fulls.append(xs_full)
             xfs.append(xf)
-        # ---- head (trunk stream; joins the fast pathway)
-        if NP == 2:
-            F_.sync(0, 1)
-        F_.cur_lane = 0
+        # ---- head: each pathway pools its own output on its own lane (disjoint column ranges of `feat`), then the trunk
+        #      joins the fast pathway for the Linear
         xs_out, xf_out = xs_full, xf
         F = self.fc_in
         feat = self._buf("feat", n * F, torch.float32)
         rate = float(spec.dropout) if train else 0.0
         ks = spec.head_pool_kernels[0]
-        pl.fwd.append(be.head_pool_fwd(xs_out, ks, rate, self.drop_seed, feat, F, 0))
         if NP == 2:
             kf = spec.head_pool_kernels[1]
+            F_.cur_lane = 1
             pl.fwd.append(be.head_pool_fwd(xf_out, kf, rate, self.drop_seed, feat, F, xs_out.c))
+        F_.cur_lane = 0
+        pl.fwd.append(be.head_pool_fwd(xs_out, ks, rate, self.drop_seed, feat, F, 0))
+        if NP == 2:
+            F_.sync(0, 1)
         assert xs_out.c + (xf_out.c if NP == 2 else 0) == F
         K = self.fc_out
         pl.logits = self._buf("logits", n * K, torch.float32)[: n * K].view(n, K)
@@ -991,12 +993,14 @@ class Engine:
                                     self._gslice(self.fc_b_off, K), n, F, K))
         pl.grad_marks.append((len(pl.bwd), (self.fc_w_off, self.layers[0].g_off - self.fc_w_off)))
         d_xs = self._fmap("d.cat.4", n, xs_out.t, xs_out.h, xs_out.w, xs_out.c)
-        pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
         d_xf = None
-        if NP == 2:
+        if NP == 2:                                     # fork: the fast pathway un-pools its own gradient on its own lane
             d_xf = self._fmap("d.xf.4", n, xf_out.t, xf_out.h, xf_out.w, xf_out.c)
+            B_.sync(1, 0)
+            B_.cur_lane = 1
             pl.bwd.append(be.head_pool_bwd(dfeat, F, xs_out.c, kf, rate, self.drop_seed, d_xf))
-            B_.sync(1, 0)                               # fork
+            B_.cur_lane = 0
+        pl.bwd.append(be.head_pool_bwd(dfeat, F, 0, ks, rate, self.drop_seed, d_xs))
         for si in range(3, -1, -1):
             # slow pathway of this stage: d_xs is the gradient of its last block's output
             B_.cur_lane = 0
