@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define SFK_ABI_VERSION 9
+/* Bumped on EVERY change of a struct layout, a prototype or the meaning of an argument / tuning field.  include/sfk.abi holds
+ * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
+ * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs. */
+#define SFK_ABI_VERSION 10
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -122,6 +125,10 @@ typedef struct {
 } sfk_conv_epilogue;
 
 typedef struct {
+  /* = sizeof(sfk_conv_desc) as the CALLER was compiled: a binding built against another layout of this struct is rejected
+   * with SFK_ERR_INVALID by every entry point that takes it, instead of reading past (or short of) what it was given */
+  uint32_t struct_size;
+  uint32_t reserved0;
   sfk_fmap x, y;
   int32_t rt, rh, rw;
   int32_t gs[3], os[3], oo[3];
@@ -160,6 +167,8 @@ int sfk_conv_igemm_family(const sfk_conv_desc* d);
  * step with sfk_fill_zero): through `workspace` when given, else with float atomics.  Same alignment rules as sfk_conv_igemm.
  */
 typedef struct {
+  uint32_t struct_size; /* = sizeof(sfk_wgrad_desc), as sfk_conv_desc.struct_size */
+  uint32_t reserved0;
   sfk_fmap x, dy;
   int32_t gs[3];
   int32_t ntaps;
@@ -282,7 +291,8 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
  *     gram = sfk_conv_wgrad(x = a[0 : c+V), dy = a[0 : c+V))  -> [c+V][c+V]: G, row c = g, element (c, c) = n
  *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz)            -> [cout][c]: R;  s = sum dz comes as partial rows from the
  *            kernel that wrote dz (its ReLU-mask pass)
- * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift exactly as sfk_bn_finalize, from `gram`; also
+ * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift as sfk_bn_finalize, from `gram` (the variance is
+ *   W Gc W^T over the CENTRED matrix Gc = G/n - (g/n)(g/n)^T formed in double: no E[y^2] - E[y]^2 cancellation); also
  *   leaves t = W G ([cout][c] fp32) for the backward and, when wd != NULL, the filter of the backward's first
  *   data-gradient pass  wd [c][cout] (w_dtype) = (A W)^T, A = gamma * invstd  -> pass 1: da = dz . wd (sfk_conv_igemm, plain).
  *   A needs the forward statistics only, so pass 1 does not wait for R: it runs beside the R filter-gradient call.
@@ -427,6 +437,8 @@ int sfk_sparse_fusion_bwd(const float* x, const float* dy, float* dw, float* db,
  * table is unchanged).  The fields only move work between equivalent kernels / grid shapes / cache hints: results keep
  * their meaning (summation order of split sums may change). */
 typedef struct {
+  uint32_t struct_size;       /* = sizeof(sfk_tuning) of the CALLER, set before sfk_default_tuning / sfk_get_tuning /
+                                 sfk_init: a mismatch is SFK_ERR_INVALID and nothing is read or written                */
   int32_t igemm_short_k;      /* 5:    exact-count K loop for layers of <= this many K-steps                      */
   int32_t igemm_small_k;      /* 0:    128x128 instead of 256x128 tiles up to this K (cin * taps)                 */
   int32_t igemm_wide_store;   /* 1:    16-byte epilogue stores                                                    */
@@ -446,9 +458,9 @@ typedef struct {
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
   int32_t wgrad_target_gen;   /* 768:  ... of the register-staged filter-gradient kernels (0 = 1024)               */
 } sfk_tuning;
-void sfk_default_tuning(sfk_tuning* out);
-int sfk_init(const sfk_tuning* t); /* NULL = defaults */
-void sfk_get_tuning(sfk_tuning* out);
+int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
+int sfk_init(const sfk_tuning* t);       /* NULL = defaults */
+int sfk_get_tuning(sfk_tuning* out);     /* out->struct_size must be set */
 
 int sfk_abi_version(void);
 const char* sfk_status_string(int status);

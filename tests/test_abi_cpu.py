@@ -38,16 +38,16 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(_lib._FMap) == 40            # void* + 8 x int32
     assert ctypes.sizeof(_lib._Tap) == 4
     assert _lib._ConvDesc.taps.size == 4 * _lib.SFK_MAX_TAPS
-    assert lib.sfk_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.sfk_abi_version() == _lib.ABI_VERSION == 10
     assert lib.sfk_status_string(0) == b"ok" and lib.sfk_status_string(-2).startswith(b"unsupported")
 
 
 def test_invalid_descriptors_are_rejected_on_the_host(lib):
     from video_classification_amd import _lib
-    d = _lib._ConvDesc()                                # all zero: null pointers
+    d = _lib.new_conv_desc()                            # all zero but the handshake: null pointers
     assert lib.sfk_conv_igemm(ctypes.byref(d), None) == -1
     assert lib.sfk_conv_igemm_mtiles(ctypes.byref(d)) == -1
-    w = _lib._WgradDesc()
+    w = _lib.new_wgrad_desc()
     assert lib.sfk_conv_wgrad(ctypes.byref(w), None) == -1
     assert lib.sfk_fc_fwd(None, None, None, None, 1, 1, 1, None) == -1
     assert lib.sfk_adam(None, None, None, None, 10, 0.1, 0.9, 0.999, 1e-8, 1.0, None, None, 0, None) == -1
@@ -108,17 +108,94 @@ def test_header_struct_sizes_match_ctypes(lib, tmp_path):
 
 def test_tuning_table_is_write_once_and_env_free(lib):
     from video_classification_amd import _lib
-    d, cur = _lib._Tuning(), _lib._Tuning()
-    lib.sfk_default_tuning(ctypes.byref(d))
-    lib.sfk_get_tuning(ctypes.byref(cur))
+    d, cur = _lib.new_tuning(), _lib.new_tuning()
+    assert lib.sfk_default_tuning(ctypes.byref(d)) == 0
+    assert lib.sfk_get_tuning(ctypes.byref(cur)) == 0
     assert (d.igemm_short_k, d.bn_parts, d.nt_reduce_mb, d.nt_bwd_apply_mb, d.pool_blocks) == (5, 1024, 48, 150, 1 << 20)
     assert lib.sfk_init(ctypes.byref(cur)) == 0            # the same table again: fine
     other = _lib._Tuning.from_buffer_copy(cur)
     other.bn_parts = cur.bn_parts + 1
     assert lib.sfk_init(ctypes.byref(other)) == -1         # a different one after load(): rejected, nothing changes
-    after = _lib._Tuning()
-    lib.sfk_get_tuning(ctypes.byref(after))
+    after = _lib.new_tuning()
+    assert lib.sfk_get_tuning(ctypes.byref(after)) == 0
     assert bytes(after) == bytes(cur)
     # the library itself does not read the environment (include/sfk.h "Conventions")
     for f in os.listdir(os.path.join(ROOT, "video-classification_amd", "csrc")):
         assert "getenv" not in open(os.path.join(ROOT, "video-classification_amd", "csrc", f)).read(), f
+
+
+def _valid_looking_conv_desc(_lib):
+    """a descriptor that passes every host-side check (the pointers are never dereferenced by the query)"""
+    d = _lib.new_conv_desc()
+    for m in (d.x, d.y):
+        m.ptr, m.dtype, m.n, m.t, m.h, m.w, m.c, m.ld, m.c_off = 0x1000, 1, 1, 2, 4, 4, 16, 16, 0
+    d.rt, d.rh, d.rw = 2, 4, 4
+    for a in range(3):
+        d.gs[a], d.os[a], d.oo[a] = 1, 1, 0
+    d.ntaps, d.w, d.wtaps, d.cin, d.cout = 1, 0x2000, 1, 16, 16
+    return d
+
+
+def test_struct_size_handshake_rejects_other_layouts(lib):
+    """SFK_ABI_VERSION stayed 9 across three layout changes in round 2: a binding written for the older sfk_wgrad_desc passed
+    the version check and handed the library a struct 48 bytes short.  Since ABI 10 the descriptors carry the caller's
+    sizeof: a stale binding gets SFK_ERR_INVALID from every entry point instead of silent garbage."""
+    from video_classification_amd import _lib
+    d = _valid_looking_conv_desc(_lib)
+    assert lib.sfk_conv_igemm_mtiles(ctypes.byref(d)) > 0                 # the same bytes with the right handshake: accepted
+    for wrong in (0, ctypes.sizeof(_lib._ConvDesc) - 8, ctypes.sizeof(_lib._ConvDesc) + 48):
+        d.struct_size = wrong
+        assert lib.sfk_conv_igemm_mtiles(ctypes.byref(d)) == -1
+        assert lib.sfk_conv_igemm(ctypes.byref(d), None) == -1
+        assert lib.sfk_conv_igemm_family(ctypes.byref(d)) == -1
+        assert lib.sfk_conv_bnb_supported(ctypes.byref(d)) == 0
+        assert lib.sfk_conv_relu_out_supported(ctypes.byref(d)) == 0
+        assert lib.sfk_conv_epilogue_supported(ctypes.byref(d)) == 0
+    w = _lib.new_wgrad_desc()
+    w.struct_size -= 48                                                     # round 2's pre-dg_w / dg_y layout
+    assert lib.sfk_conv_wgrad(ctypes.byref(w), None) == -1
+    assert lib.sfk_conv_wgrad_workspace_bytes(ctypes.byref(w)) == -1
+    assert lib.sfk_conv_wgrad_dg_supported(ctypes.byref(w)) == 0
+    t = _lib.new_tuning()
+    t.struct_size += 4
+    assert lib.sfk_default_tuning(ctypes.byref(t)) == -1
+    assert lib.sfk_get_tuning(ctypes.byref(t)) == -1
+    assert lib.sfk_init(ctypes.byref(t)) == -1
+
+
+def test_header_hash_is_locked_to_the_abi_version():
+    """include/sfk.abi = (version, hash of the header's declarations): editing a struct, a prototype or a constant without
+    bumping SFK_ABI_VERSION fails here; tools/abi_lock.py --write refuses to re-lock an already locked version number."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("abi_lock", os.path.join(ROOT, "tools", "abi_lock.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    version, digest = mod.header_state()
+    assert mod.locked() == (version, digest), \
+        "include/sfk.h's declarations changed: bump SFK_ABI_VERSION (and _lib.ABI_VERSION, INTEGRATION.md), then tools/abi_lock.py --write"
+    from video_classification_amd import _lib
+    assert version == _lib.ABI_VERSION
+    # comments and whitespace do not move the hash; a layout edit does
+    src = open(mod.HEADER).read()
+    assert mod.declarations(src + "\n/* a remark */\n") == mod.declarations(src)
+    assert mod.declarations(src.replace("int32_t wtaps, cin, cout;", "int32_t wtaps, cout, cin;", 1)) != mod.declarations(src)
+
+
+def test_streaming_pointwise_routes_refuse_maps_beyond_32_bit_offsets(lib):
+    """the streaming pointwise kernels (conv_pw.hip) read the old rows of a `+=` pass through a 32-bit buffer resource; a map of
+    4 GiB or more must stay on the implicit-GEMM kernel (64-bit epilogue pointers) instead of wrapping silently.  Host-side
+    routing only: nothing is launched, the pointers are never dereferenced."""
+    from video_classification_amd import _lib
+    d = _lib.new_conv_desc()
+    n, t, h, w, c = 4, 8, 56, 56, 64
+    for m in (d.x, d.y):
+        m.ptr, m.dtype, m.n, m.t, m.h, m.w, m.c, m.ld, m.c_off = 0x10000, 1, n, t, h, w, c, c, 0
+    d.rt, d.rh, d.rw = t, h, w
+    for a in range(3):
+        d.gs[a], d.os[a], d.oo[a] = 1, 1, 0
+    d.ntaps, d.w, d.wtaps, d.cin, d.cout, d.accumulate = 1, 0x20000, 1, c, c, 1
+    assert lib.sfk_conv_igemm_family(ctypes.byref(d)) == 3             # K = cout = 64, += : the streaming kernel
+    d.y.ld = (1 << 32) // (2 * n * t * h * w) + 8                      # same logical map inside >= 4 GiB of pixel records
+    d.y.ld -= d.y.ld % 8
+    assert d.y.ld * 2 * n * t * h * w >= (1 << 32) - 64
+    assert lib.sfk_conv_igemm_family(ctypes.byref(d)) in (0, 1)        # implicit GEMM, not the 32-bit streaming route

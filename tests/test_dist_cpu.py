@@ -169,3 +169,34 @@ def test_trainer_shards_epoch_and_eval_over_two_ranks(tmp_path):
         assert (r["t"] == one["t"]).all() and abs(r["ps"] - one["ps"]).max() < 1e-6
     files = os.listdir(tmp_path / "logs" / "checkpoints" / "slowfast-LHand")
     assert files == ["acc0.500_e1.ckpt"]
+
+
+def _tiny_eval_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from emu_backend import EmuBackend
+    from video_classification_amd.train import SyntheticChalearn, Trainer
+    cfg = _trainer_cfg(out_dir)
+    tr = SyntheticChalearn(cfg, "train", num_videos=4, seed=1)
+    te = SyntheticChalearn(cfg, "test", num_videos=1, clips_per_video=(2, 2), seed=2)     # fewer videos than ranks
+    t = Trainer(cfg, train_set=tr, test_set=te, device="cpu", backend=EmuBackend(), dist_backend="gloo")
+    ev = t.run_eval()                                        # rank 1's shard is EMPTY: it must still reach the gather
+    torch.save(ev, os.path.join(out_dir, f"tiny_eval_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eval_with_fewer_videos_than_ranks_does_not_hang(tmp_path):
+    """VideoShardSampler pads nothing: with one test video and two ranks, rank 1 evaluates no clip at all.  It used to raise in
+    torch.cat([]) while rank 0 waited in all_gather_object; now it contributes zero rows and both ranks return the 1-rank dict."""
+    world, port = 2, _free_port()
+    mp.spawn(_tiny_eval_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / "tiny_eval_rank0.pt", weights_only=False)
+    b = torch.load(tmp_path / "tiny_eval_rank1.pt", weights_only=False)
+    assert a["sv"] == b["sv"] == [2] and a["acc"] == b["acc"]
+    assert a["ps"].shape == b["ps"].shape == (2, 5) and abs(a["ps"] - b["ps"]).max() == 0
+    assert (a["t"] == b["t"]).all()

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 9        # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 10       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -168,7 +168,7 @@ class _ConvEpilogue(C.Structure):
 
 
 class _ConvDesc(C.Structure):
-    _fields_ = [("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("x", _FMap), ("y", _FMap), ("rt", C.c_int32), ("rh", C.c_int32), ("rw", C.c_int32),
                 ("gs", C.c_int32 * 3), ("os", C.c_int32 * 3), ("oo", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("w", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("bnb", _BnBwdFuse),
@@ -176,7 +176,7 @@ class _ConvDesc(C.Structure):
 
 
 class _WgradDesc(C.Structure):
-    _fields_ = [("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("x", _FMap), ("dy", _FMap), ("gs", C.c_int32 * 3), ("ntaps", C.c_int32),
                 ("taps", _Tap * SFK_MAX_TAPS), ("dw", C.c_void_p), ("wtaps", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("dg_w", C.c_void_p), ("dg_y", _FMap)]
@@ -191,7 +191,7 @@ class _StemSrc(C.Structure):
 
 class _Tuning(C.Structure):
     """sfk_tuning: the write-once kernel-selection table of sfk_init (defaults = the measured best)."""
-    _fields_ = [("igemm_short_k", C.c_int32), ("igemm_small_k", C.c_int32), ("igemm_wide_store", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("igemm_short_k", C.c_int32), ("igemm_small_k", C.c_int32), ("igemm_wide_store", C.c_int32),
                 ("wgrad_target_8w", C.c_int32), ("wgrad_target_4w", C.c_int32), ("wgrad_use_workspace", C.c_int32),
                 ("wgrad_wide_co", C.c_int32), ("bn_parts", C.c_int32), ("nt_apply_mb", C.c_int32),
                 ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("igemm_pw_stream", C.c_int32),
@@ -260,8 +260,26 @@ SIGNATURES = {
     "sfk_abi_version": [],
     "sfk_status_string": [C.c_int],
 }
-_RESTYPE = {"sfk_status_string": C.c_char_p, "sfk_conv_wgrad_workspace_bytes": C.c_int64, "sfk_default_tuning": None,
-            "sfk_get_tuning": None}
+_RESTYPE = {"sfk_status_string": C.c_char_p, "sfk_conv_wgrad_workspace_bytes": C.c_int64}
+
+
+def new_conv_desc() -> "_ConvDesc":
+    """a zeroed sfk_conv_desc carrying the ABI handshake (struct_size = the layout THIS binding was written for)"""
+    d = _ConvDesc()
+    d.struct_size = C.sizeof(_ConvDesc)
+    return d
+
+
+def new_wgrad_desc() -> "_WgradDesc":
+    d = _WgradDesc()
+    d.struct_size = C.sizeof(_WgradDesc)
+    return d
+
+
+def new_tuning() -> "_Tuning":
+    t = _Tuning()
+    t.struct_size = C.sizeof(_Tuning)
+    return t
 
 _lib = None
 
@@ -280,9 +298,10 @@ def load(path: str = LIB_PATH) -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = _RESTYPE[name] if name in _RESTYPE else C.c_int
     if lib.sfk_abi_version() != ABI_VERSION:
-        raise SfkError("libsfk ABI version mismatch")
-    t = _Tuning()
-    lib.sfk_default_tuning(C.byref(t))
+        raise SfkError(f"libsfk ABI version mismatch: library {lib.sfk_abi_version()}, binding {ABI_VERSION}")
+    t = new_tuning()
+    if lib.sfk_default_tuning(C.byref(t)) != 0:
+        raise SfkError("sfk_default_tuning refused this binding's sfk_tuning layout")
     for env, fld in TUNING_ENV.items():
         if os.environ.get(env) is not None:
             setattr(t, fld, int(os.environ[env]))
@@ -295,8 +314,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
 
 def tuning() -> _Tuning:
     """the table the loaded library runs with (sfk_get_tuning)"""
-    t = _Tuning()
-    load().sfk_get_tuning(C.byref(t))
+    t = new_tuning()
+    _check(load().sfk_get_tuning(C.byref(t)), "sfk_get_tuning")
     return t
 
 
@@ -323,7 +342,7 @@ def _c_taps(taps: Sequence[Tap]):
 
 
 def _c_conv(p: ConvPass) -> _ConvDesc:
-    d = _ConvDesc()
+    d = new_conv_desc()
     d.x, d.y = _c_fmap(p.x), _c_fmap(p.y)
     d.rt, d.rh, d.rw = p.rows
     d.gs = (C.c_int32 * 3)(*p.gs)
@@ -408,7 +427,7 @@ class HipBackend:
         return run
 
     def _wgrad_desc(self, p: WgradPass):
-        d = _WgradDesc()
+        d = new_wgrad_desc()
         d.x, d.dy = _c_fmap(p.x), _c_fmap(p.dy)
         d.gs = (C.c_int32 * 3)(*p.gs)
         d.ntaps, d.taps = len(p.taps), _c_taps(p.taps)

@@ -22,7 +22,8 @@ template <typename D> __device__ __forceinline__ float wload(const void* w, int6
 constexpr int TF_CO = 8;      // output channels per block of the forward kernel
 constexpr int TF_MAXC = 512;  // widest conv_c input of the ResNet-50/101/152 SlowFast family (2048 / 4)
 
-// T[co][:] = W[co][:] G,  m1 = W[co] . g / n,  m2 = T[co] . W[co] / n  for TF_CO channels per block; thread <-> column ci
+// T[co][:] = W[co][:] G,  mean = W[co] . g / n,  var = W[co] Gc W[co]^T (Gc = the centred Gram matrix)  for TF_CO channels per
+// block; thread <-> column ci
 template <typename D>
 __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restrict__ gram, int c, int gld, const void* w,
                                                           int cout, const float* gamma, const float* beta, float eps,
@@ -30,38 +31,55 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
                                                           int64_t* nbt, float* mean, float* invstd, float* scale,
                                                           float* shift, float* __restrict__ t, D* __restrict__ wd) {
   __shared__ float wl[TF_CO][TF_MAXC];
+  __shared__ float gl[TF_MAXC];        // column means g / n
   __shared__ double red[4 * TF_CO][2];
   __shared__ float acoef[TF_CO];
   const int co0 = blockIdx.x * TF_CO, tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0 && nbt) nbt[0] += 1;
+  const double n = (double)gram[(int64_t)c * gld + c], inv_n = 1.0 / n;
   for (int i = tid; i < TF_CO * c; i += 256) {
     const int o = i / c, j = i % c;
     wl[o][j] = co0 + o < cout ? wload<D>(w, (int64_t)(co0 + o) * c + j) : 0.f;
   }
+  for (int j = tid; j < c; j += 256) gl[j] = (float)((double)gram[(int64_t)c * gld + j] * inv_n);
   __syncthreads();
   constexpr int NR = TF_MAXC / 256;
-  float acc[TF_CO][NR];
+  // acc = T = W G (the backward's operand).  The VARIANCE is not taken from it: E[y^2] - E[y]^2 cancels mean^2 / var digits of an
+  // fp32 T (1e-4 relative at mean^2 / var = 1e4; a near-constant channel clamps to var = 0, invstd = 1 / sqrt(eps)).  accc sums the
+  // CENTRED matrix  Gc = G / n - (g / n)(g / n)^T  -- each entry formed in double, so the products are covariances, small
+  // against nothing -- and var = W Gc W^T needs no subtraction.
+  float acc[TF_CO][NR], accc[TF_CO][NR];
+  double gbar[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int ci = tid + 256 * r;
+    gbar[r] = ci < c ? (double)gram[(int64_t)c * gld + ci] * inv_n : 0.0;
+  }
 #pragma unroll
   for (int o = 0; o < TF_CO; ++o)
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[o][r] = 0.f;
+    for (int r = 0; r < NR; ++r) { acc[o][r] = 0.f; accc[o][r] = 0.f; }
 #pragma unroll 8                       // 8 rows of G in flight: the loop is bound by the latency of these loads
   for (int j = 0; j < c; ++j) {
-    float gj[NR];
+    float gj[NR], gc[NR];
+    const double mj = (double)gl[j];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int ci = tid + 256 * r;
       gj[r] = ci < c ? gram[(int64_t)j * gld + ci] : 0.f;
+      gc[r] = (float)((double)gj[r] * inv_n - mj * gbar[r]);
     }
 #pragma unroll
     for (int o = 0; o < TF_CO; ++o) {
       const float wv = wl[o][j];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) acc[o][r] += wv * gj[r];
+      for (int r = 0; r < NR; ++r) {
+        acc[o][r] += wv * gj[r];
+        accc[o][r] += wv * gc[r];
+      }
     }
   }
-  const double n = (double)gram[(int64_t)c * gld + c];
-  // per channel: p1 = W[co] . g, p2 = T[co] . W[co]; wave butterflies in double, then 4 waves through LDS (fixed order)
+  // per channel: p1 = W[co] . g, p2 = (W Gc)[co] . W[co]; wave butterflies in double, then 4 waves through LDS (fixed order)
   double p1[TF_CO], p2[TF_CO];
 #pragma unroll
   for (int o = 0; o < TF_CO; ++o) {
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
       if (ci < c) {
         if (co0 + o < cout) t[(int64_t)(co0 + o) * c + ci] = acc[o][r];
         p1[o] += (double)wl[o][ci] * (double)gram[(int64_t)c * gld + ci];
-        p2[o] += (double)acc[o][r] * (double)wl[o][ci];
+        p2[o] += (double)accc[o][r] * (double)wl[o][ci];
       }
     }
 #pragma unroll
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
     const double s1 = red[tid][0] + red[TF_CO + tid][0] + red[2 * TF_CO + tid][0] + red[3 * TF_CO + tid][0];
     const double s2 = red[tid][1] + red[TF_CO + tid][1] + red[2 * TF_CO + tid][1] + red[3 * TF_CO + tid][1];
     const double mu = s1 / n;
-    double var = s2 / n - mu * mu;
+    double var = s2;                    // = W Gc W^T: already centred (see accc)
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[ch] * is;

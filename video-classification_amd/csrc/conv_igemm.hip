@@ -1101,6 +1101,9 @@ inline bool pw_plain_route(const sfk_conv_desc* d) {
   if (d->x.dtype != SFK_BF16 || !sfk_tune().igemm_pw_stream || (sfk_tune().igemm_pw_stream & 8) || d->stats || d->bnb.partials ||
       d->out_relu_bits || d->ep.res.ptr || d->ep.relu || d->ep.scale || !pointwise_lin(d) || (d->y.ld % 8) || (d->y.c_off % 8))
     return false;
+  // the streaming kernel reads the old rows of a += pass through a 32-bit buffer resource (validate() bounds y only for
+  // fused epilogues): maps of 4 GiB and more stay on the implicit GEMM, whose epilogue uses 64-bit pointers
+  if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64) return false;
   return (d->cout == 64 && d->cin == 64) || (d->cout == 128 && d->cin == 128);
 }
 // rows of the streaming data-gradient kernel (accumulate + bitmap mask + column sums), 0 when the pass is not one of its
@@ -1112,7 +1115,8 @@ inline int pw_dgrad_rows(const sfk_conv_desc* d) {
 }
 
 int validate(const sfk_conv_desc* d) {
-  if (!d || !d->w) return SFK_ERR_INVALID;
+  if (!d || d->struct_size != sizeof(sfk_conv_desc)) return SFK_ERR_INVALID;   // ABI handshake: the caller's layout is ours
+  if (!d->w) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->y)) return SFK_ERR_INVALID;
   if (d->x.dtype != d->y.dtype || d->x.n != d->y.n) return SFK_ERR_INVALID;
   if (d->cin != d->x.c || d->cout != d->y.c) return SFK_ERR_INVALID;
@@ -1322,7 +1326,7 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
 }
 
 extern "C" int sfk_conv_relu_out_supported(const sfk_conv_desc* d) {
-  if (!d) return 0;
+  if (!d || d->struct_size != sizeof(sfk_conv_desc)) return 0;
   sfk_conv_desc c = *d;
   c.out_relu_bits = nullptr;
   if (validate(&c) != SFK_OK) return 0;
@@ -1348,7 +1352,7 @@ extern "C" int sfk_conv_epilogue_supported(const sfk_conv_desc* d) {
 }
 
 extern "C" int sfk_conv_bnb_supported(const sfk_conv_desc* d) {
-  if (!d) return 0;
+  if (!d || d->struct_size != sizeof(sfk_conv_desc)) return 0;
   sfk_conv_desc c = *d;
   c.bnb.partials = nullptr;
   if (validate(&c) != SFK_OK) return 0;

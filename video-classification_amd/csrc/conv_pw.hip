@@ -281,6 +281,9 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   const sfk_conv_epilogue& e = d->ep;
   const int K = d->cin, C = d->cout;
   if (K > 128 || (K % 8) != 0) return SFK_ERR_UNSUPPORTED;
+  // every map is addressed through a 32-bit buffer resource (y too: the old rows of a += pass are READ through one); a map
+  // of 4 GiB or more would wrap silently -- the implicit-GEMM kernels, which write through 64-bit pointers, take those
+  if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64 || sfk_fmap_bytes(&d->x) >= (1ll << 32) - 64) return SFK_ERR_UNSUPPORTED;
   const int KS = (K + 31) / 32;
   PwK k;
   k.x = d->x.ptr; k.y = d->y.ptr; k.w = d->w; k.res = e.res.ptr;
@@ -313,6 +316,7 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
 // The data-gradient flavour (DG): shapes (dY channels -> dX channels) (64 -> 256) and (128 -> 512), the pointwise conv_a of the
 // slow pathway's res2 / res3.  sfk_conv_pw_dgrad_rows: partial rows such a launch leaves (0: not a shape of this kernel).
 int sfk_conv_pw_dgrad_rows(const sfk_conv_desc* d) {
+  if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64 || sfk_fmap_bytes(&d->x) >= (1ll << 32) - 64) return 0;   // 32-bit buffer resources
   const int M = (int)sfk_fmap_pixels(&d->y);
   if (d->cin == 64 && d->cout == 256) return pw_blocks(M, 2, 256) * 4 / 2;
   if (d->cin == 128 && d->cout == 512) return pw_blocks(M, 8, 512) * 8 / 8;

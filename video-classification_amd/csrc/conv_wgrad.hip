@@ -639,7 +639,8 @@ bool dg_ok(const sfk_wgrad_desc* d) {
 }
 
 int validate(const sfk_wgrad_desc* d) {
-  if (!d || !d->dw) return SFK_ERR_INVALID;
+  if (!d || d->struct_size != sizeof(sfk_wgrad_desc)) return SFK_ERR_INVALID;   // ABI handshake (include/sfk.h)
+  if (!d->dw) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(&d->x) || !sfk_fmap_ok(&d->dy)) return SFK_ERR_INVALID;
   if (d->x.dtype != d->dy.dtype || d->x.n != d->dy.n) return SFK_ERR_INVALID;
   if (d->cin != d->x.c || d->cout != d->dy.c) return SFK_ERR_INVALID;

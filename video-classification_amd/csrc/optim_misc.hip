@@ -202,23 +202,31 @@ extern "C" int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream) {
 
 // ------------------------------------------------------------------ tuning table (sfk_init)
 namespace {
-sfk_tuning g_tuning = {5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 768};
+constexpr sfk_tuning kDefaults = {(uint32_t)sizeof(sfk_tuning), 5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 768};
+sfk_tuning g_tuning = kDefaults;
 bool g_tuning_set = false;
 }  // namespace
 const sfk_tuning& sfk_tune() { return g_tuning; }
 
-extern "C" void sfk_default_tuning(sfk_tuning* out) {
-  if (out) *out = sfk_tuning{5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 768};
+// struct_size is the caller's sizeof(sfk_tuning): a binding compiled against another layout is refused before a byte moves
+extern "C" int sfk_default_tuning(sfk_tuning* out) {
+  if (!out || out->struct_size != sizeof(sfk_tuning)) return SFK_ERR_INVALID;
+  *out = kDefaults;
+  return SFK_OK;
 }
 
-extern "C" void sfk_get_tuning(sfk_tuning* out) {
-  if (out) *out = g_tuning;
+extern "C" int sfk_get_tuning(sfk_tuning* out) {
+  if (!out || out->struct_size != sizeof(sfk_tuning)) return SFK_ERR_INVALID;
+  *out = g_tuning;
+  return SFK_OK;
 }
 
 extern "C" int sfk_init(const sfk_tuning* t) {
-  sfk_tuning want;
-  sfk_default_tuning(&want);
-  if (t) want = *t;
+  sfk_tuning want = kDefaults;
+  if (t) {
+    if (t->struct_size != sizeof(sfk_tuning)) return SFK_ERR_INVALID;
+    want = *t;
+  }
   if (want.bn_parts < 1 || want.wgrad_target_8w < 1 || want.wgrad_target_4w < 1 || want.pool_blocks < 1 ||
       want.igemm_short_k < 0)
     return SFK_ERR_INVALID;

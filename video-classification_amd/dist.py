@@ -61,8 +61,15 @@ def split_ranges(ranges: Sequence[Range], max_numel: int) -> List[Range]:
 
 
 class GradReducer:
-    """All-reduces ranges of a flat gradient tensor.  `reduce(ranges)` may be called several times per step
-    (once per finished backward segment); `finish()` makes the caller's stream wait for all of them."""
+    """All-reduces ranges of a flat gradient tensor while backward is still running.  `reduce(ranges, ...)` is called once per
+    finished backward segment; `finish()` makes the caller's stream wait for all of them.
+
+    No relay stream: a process gets FOUR hardware queues (GPU_MAX_HW_QUEUES) and streams beyond that share one and serialise
+    (measured on one MI355X: a fifth active stream costs 2 %, eight queues 28 %).  ProcessGroupNCCL
+    (= RCCL) runs every collective on ITS OWN internal stream whatever stream issued it, so that stream is the fourth queue:
+    the step keeps three compute lanes when world > 1 (trunk, fast pathway, ONE filter-gradient lane -- `Engine.wgrad_one_lane`,
+    measured neutral single-rank) and the buckets are issued with ``async_op=True`` from the filter-gradient lane, which
+    first waits (events) for the other producers of the segment.  The lane itself never waits for the collective."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, bucket_mb: float = 32.0):
         self.g = flat_grad
@@ -70,70 +77,94 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_numel = max(1, int(bucket_mb * (1 << 20) / flat_grad.element_size()))
         self.cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(flat_grad.device) if self.cuda else None
         self.reduced: List[Range] = []
+        self.handles: list = []
+
+    @property
+    def active(self) -> bool:
+        """does the step run its segmented backward (cuts, waits, buckets) for this reducer?"""
+        return self.world > 1
+
+    @property
+    def grad_scale(self) -> float:
+        """what Adam multiplies the exchanged gradients by (SUM -> mean)"""
+        return 1.0 / self.world
 
     def begin(self):
         self.reduced = []
+        self.handles = []
 
-    def reduce(self, ranges: Sequence[Range], producers: Optional[Sequence["torch.cuda.Stream"]] = None):
-        """producers: the streams that wrote these gradient ranges (default: the current stream); the exchange
-        starts once everything issued on them so far has finished."""
-        if self.world == 1:
+    def _order_after(self, issue, producers):
+        """`issue` waits for everything issued so far on the producer streams"""
+        for s in producers:
+            if s is not issue:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                issue.wait_event(ev)
+
+    def reduce(self, ranges: Sequence[Range], producers: Optional[Sequence["torch.cuda.Stream"]] = None, issue_on=None):
+        """producers: the streams that wrote these gradient ranges (default: the current stream).  issue_on: the lane the
+        buckets are enqueued from (default: the current stream); it waits for the producers, the collective's own stream
+        waits for it, and nobody waits for the collective until finish()."""
+        if not self.active:
             return
         ranges = split_ranges(merge_ranges(ranges), self.bucket_numel)
         self.reduced += ranges
         if self.cuda:
-            evs = []
-            for s in (producers or [torch.cuda.current_stream(self.g.device)]):
-                ev = torch.cuda.Event()
-                ev.record(s)
-                evs.append(ev)
-            with torch.cuda.stream(self.comm_stream):
-                for ev in evs:
-                    self.comm_stream.wait_event(ev)
+            cur = torch.cuda.current_stream(self.g.device)
+            issue = issue_on if issue_on is not None else cur
+            self._order_after(issue, producers or [cur])
+            with torch.cuda.stream(issue):
                 for off, n in ranges:
-                    dist.all_reduce(self.g[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+                    self.handles.append(dist.all_reduce(self.g[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
+                                                        async_op=True))
         else:
             for off, n in ranges:
                 dist.all_reduce(self.g[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
 
     def finish(self) -> float:
-        """Returns the factor the optimiser must scale gradients by (1/world: SUM -> mean)."""
-        if self.world > 1 and self.cuda:
-            torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
-        return 1.0 / self.world
+        """The caller's stream waits for every bucket.  Returns grad_scale (1/world: SUM -> mean)."""
+        for h in self.handles:
+            h.wait()                     # NCCL: the CURRENT stream waits for the collective's stream (no host block)
+        self.handles = []
+        return self.grad_scale
 
 
 class LoopbackReducer(GradReducer):
-    """Single-process REHEARSAL of the overlapped gradient exchange (bench.py --rehearse-comm): the same segment cuts, event
-    waits, comm stream and bucket sizes as GradReducer with world ranks, but each bucket's all-reduce is replaced by a local
-    memory-bound stand-in on the comm stream (a ring all-reduce moves 2 (world-1)/world of the bucket in and out of HBM: here
-    one read-modify-write of the bucket against a scratch copy).  It measures what the fifth stream costs the step on ONE GPU
-    -- queue sharing, CU and HBM contention -- not the xGMI transfer time; gradients are left unchanged in value (x + 0)."""
+    """Single-process REHEARSAL of the overlapped gradient exchange (bench.py --rehearse-comm): the segment cuts, event waits,
+    issue lane and bucket sizes of GradReducer at `rehearse_world` ranks, with each bucket's all-reduce replaced by a local
+    memory-bound stand-in on ONE extra stream that plays ProcessGroupNCCL's internal stream (a ring all-reduce moves
+    2 (world-1)/world of the bucket in and out of HBM: here one read-modify-write of the bucket against a scratch copy).  It
+    prices the fourth queue on ONE GPU -- queue sharing, CU and HBM contention -- not the xGMI transfer.  Gradients keep their
+    values (x + 0) and `world` stays 1, so Adam's gradient scale is 1 and the rehearsed step trains exactly as the plain one."""
 
     def __init__(self, flat_grad: torch.Tensor, world: int = 8, bucket_mb: float = 32.0):
         super().__init__(flat_grad, None, bucket_mb)
-        self.world = world
+        self.world = 1
+        self.rehearse_world = world
+        self.comm_stream = torch.cuda.Stream(flat_grad.device)
         self.scratch = torch.zeros(self.bucket_numel, dtype=flat_grad.dtype, device=flat_grad.device)
 
-    def reduce(self, ranges, producers=None):
+    @property
+    def active(self) -> bool:
+        return True
+
+    def reduce(self, ranges, producers=None, issue_on=None):
         ranges = split_ranges(merge_ranges(ranges), self.bucket_numel)
         self.reduced += ranges
-        evs = []
-        for s in (producers or [torch.cuda.current_stream(self.g.device)]):
-            ev = torch.cuda.Event()
-            ev.record(s)
-            evs.append(ev)
+        cur = torch.cuda.current_stream(self.g.device)
+        issue = issue_on if issue_on is not None else cur
+        self._order_after(issue, producers or [cur])
+        ev = torch.cuda.Event()
+        ev.record(issue)
+        self.comm_stream.wait_event(ev)            # the collective's stream waits for the issuing lane, as RCCL's does
         with torch.cuda.stream(self.comm_stream):
-            for ev in evs:
-                self.comm_stream.wait_event(ev)
             for off, n in ranges:
                 self.g[off:off + n].add_(self.scratch[:n])
 
     def finish(self) -> float:
         torch.cuda.current_stream(self.g.device).wait_stream(self.comm_stream)
-        return 1.0
+        return self.grad_scale
 
 
 def shard_indices(num_items: int, rank: int, world: int, epoch_seed: int, shuffle: bool = True,

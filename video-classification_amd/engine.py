@@ -142,6 +142,9 @@ class Engine:
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
+        # both pathways' filter gradients on ONE lane (lane 2): three compute streams, so that the collective's stream of a
+        # world > 1 step is the fourth hardware queue (dist.GradReducer; single-rank: 1078 vs 1077 clips/s, neutral)
+        self.wgrad_one_lane = os.environ.get("SFK_WGRAD_LANES", "1") == "2"
         self.relu_bits = os.environ.get("SFK_RELU_BITS", "1") != "0"       # block-output ReLU masks kept as bitmaps
         # ... and applied by the data-gradient pass that finishes the gradient of an identity-shortcut block's output
         # (sfk_conv_desc.out_relu_bits): that block's BatchNorm backward then reads dz as it is, no mask, no rewrite
@@ -455,7 +458,7 @@ class Engine:
         # dependency chain (BN backward -> dgrad -> BN backward ...) for a lane of their own and fill the gaps that chain
         # leaves on the chip; the lane waits for the producer of dy, everything joins before the optimiser.
         home = pl.bwd.cur_lane
-        wl = home + 2 if self.wgrad_lanes else home
+        wl = (2 if self.wgrad_one_lane else home + 2) if self.wgrad_lanes else home
         if wl != home:
             pl.bwd.sync(wl, home)
             pl.bwd.cur_lane = wl

@@ -44,7 +44,11 @@ class TrainStep:
         self.eng, self.lr, self.betas, self.eps = engine, lr, betas, eps
         self.reducer = reducer
         self.world = reducer.world if reducer is not None else 1
-        self.use_graph = use_graph and self.world == 1 and engine.device.type == "cuda"
+        self.segmented = reducer is not None and reducer.active     # cut backward into segments and exchange them as they finish
+        if self.segmented:
+            # three compute lanes + the collective's own stream = the four hardware queues a process gets (dist.GradReducer)
+            engine.wgrad_one_lane = True
+        self.use_graph = use_graph and not self.segmented and engine.device.type == "cuda"
         self.overlap_segments = overlap_segments
         dev = engine.device
         self.loss = torch.zeros(1, device=dev)            # mean loss of the last step
@@ -68,7 +72,7 @@ class TrainStep:
         eng = self.eng
         ops = dict(
             loss=eng.loss_ops(pl, labels, self.loss, self.loss_sum, self.correct),
-            adam=eng.adam_ops(self.lr, self.betas, self.eps, 1.0 / self.world),
+            adam=eng.adam_ops(self.lr, self.betas, self.eps, self.reducer.grad_scale if self.reducer is not None else 1.0),
             zero_loss=eng.be.fill_zero(self.loss),
             zero_grad=eng.be.fill_zero(eng.G),
         )
@@ -82,13 +86,15 @@ class TrainStep:
         ops["zero_loss"](st)
         ops["loss"](st)
         ops["zero_grad"](st)
-        if self.world == 1:
+        if not self.segmented:
             eng._run_lanes(pl.bwd)
         else:
             self.reducer.begin()
+            lanes = eng.lane_streams()
+            issue = lanes[2] if len(lanes) > 2 else None     # the filter-gradient lane enqueues the buckets (no relay stream)
             for a, b, ranges in pl.grad_segments(self.overlap_segments):
-                eng._run_lanes(pl.bwd, a, b)          # both pathway streams, as the single-rank step
-                self.reducer.reduce(ranges, eng.lane_streams())
+                eng._run_lanes(pl.bwd, a, b)          # the pathway lanes and the filter-gradient lane, as the single-rank step
+                self.reducer.reduce(ranges, lanes, issue_on=issue)
             self.reducer.finish()
         ops["adam"](st)
 
@@ -452,9 +458,17 @@ class Trainer:
                 break
         if len(batch_collect) > 0:
             test_batch(default_collate(batch_collect))
-        logits = torch.cat(logit_list, dim=0).contiguous()
-        labels = torch.cat(true_list, dim=0).to(torch.int64).contiguous()
+        if logit_list:
+            logits = torch.cat(logit_list, dim=0).contiguous()
+            labels = torch.cat(true_list, dim=0).to(torch.int64).contiguous()
+        else:
+            # a rank whose shard holds no video (fewer test videos than ranks): zero rows, so that it still takes part in
+            # the gather below instead of raising while the other ranks wait in all_gather_object
+            logits = torch.zeros(0, int(self.cfg.CHALEARN.NUM_CLASS), dtype=torch.float32, device=self.device)
+            labels = torch.zeros(0, dtype=torch.int64, device=self.device)
         shard = getattr(loader, "sfk_shard", None)
+        # (debug mode stops after a few loader steps on every rank; the shards are then partial, nothing is gathered and each
+        # rank reports the accuracy of its own videos -- harmless: only rank 0 writes checkpoints, debug writes none)
         if shard is not None and shard[1] > 1 and not self.debug:
             logits, labels, samples_per_video = self._gather_eval(logits, labels, samples_per_video, shard)
         if hasattr(self.model, "engine"):
