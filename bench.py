@@ -130,7 +130,7 @@ def instrumented_step(step, pl, frames, labels, idx, schedule="lanes", only=None
         body()
     torch.cuda.synchronize()
     out = {}
-    if per_layer:
+    if per_layer and only is None:          # (the dominant-class-only pass must not overwrite the full dump)
         rows = [dict(meta, ms=a.elapsed_time(b)) for meta, a, b in ev]
         path = os.environ["SFK_PER_LAYER"] + ("" if schedule == "serial" else ".lanes")
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
@@ -152,27 +152,40 @@ def instrumented_step(step, pl, frames, labels, idx, schedule="lanes", only=None
     return out
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """The oracle's training step (forward, CE, backward, Adam; reference train.py:225-231) at the metric geometry,
-    fp32, on the host cores.  Bounded sample: 1 clip per step, one warm-up step, then steps until ~budget_s."""
+def cpu_model_string() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline():
+    """the oracle's training step (forward, CE, backward, Adam; reference train.py:225-231) at the
+    metric geometry, fp32, on the host cores of THIS node, in the same job as the GPU measurement.  Bounded sample: N = 2
+    clips per step, 1 warm-up + 2 timed steps; clips/s = 2 N / dt.  The line carries torch.get_num_threads(), os.cpu_count()
+    and the CPU model string."""
     from oracle import my_slowfast as o
     torch.manual_seed(1234)
     model = o.canonical_slowfast_8x8(400)
     optim = torch.optim.Adam(model.parameters(), lr=2e-4)
-    frames = torch.randn(1, 3, 32, 224, 224)
-    labels = torch.randint(0, 400, (1,))
+    n, timed = 2, 2
+    frames = torch.randn(n, 3, 32, 224, 224)
+    labels = torch.randint(0, 400, (n,))
     x = o.pack_pathway(frames)
-    t0 = time.time()
     o.train_step(model, optim, x, labels)
-    warm = time.time() - t0
-    nsteps = max(1, min(4, int(budget_s / max(warm, 1e-3))))
     t0 = time.time()
-    for _ in range(nsteps):
+    for _ in range(timed):
         o.train_step(model, optim, x, labels)
     dt = time.time() - t0
-    return {"value": round(nsteps / dt, 4), "unit": "clips/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{nsteps} training step(s) of 1 clip (3x32x224^2, fp32) after 1 warm-up step; "
-                      f"torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+    return {"value": round(timed * n / dt, 4), "unit": "clips/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model_string(), "os_cpu_count": os.cpu_count(),
+            "sample": f"{timed} training steps of {n} clips (3x32x224^2, fp32) after 1 warm-up step, {dt:.1f} s; "
+                      f"torch {torch.__version__} CPU"}
 
 
 def main():

@@ -9,6 +9,12 @@ STEPS=${STEPS:-10}; WARM=${WARM:-3}
 timeout -k 10 600 python bench.py --gpus 1 --steps $STEPS --warmup $WARM ${BENCH_ARGS:-} > gpurun_out/bench_default.log 2>&1
 rc=$?; echo "bench exit $rc"; tail -n 1 gpurun_out/bench_default.log | cut -c1-600
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
+# per-layer view of the same tree (serial + production lanes): profiles/rNN_per_layer.txt (MFMA utilisation of the MFMA-bound
+# conv layers, HBM GB/s of the BatchNorm / pool stages, lane sums)
+SFK_PER_LAYER=gpurun_out/per_layer.json timeout -k 10 600 python bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/bench_per_layer.log 2>&1
+rc=$?; echo "per-layer exit $rc"
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
+python tools/per_layer_report.py gpurun_out/per_layer.json gpurun_out/per_layer.txt && head -n 22 gpurun_out/per_layer.txt
 rm -rf gpurun_out/prof/*
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline > gpurun_out/bench_traced.log 2>&1
 rc=$?; echo "rocprof exit $rc"; tail -n 1 gpurun_out/bench_traced.log | cut -c1-300
