@@ -36,8 +36,9 @@ extern "C" {
 
 /* Bumped on EVERY change of a struct layout, a prototype or the meaning of an argument / tuning field.  include/sfk.abi holds
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
- * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs. */
-#define SFK_ABI_VERSION 10
+ * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
+ * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 / igemm_pipe. */
+#define SFK_ABI_VERSION 11
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -192,6 +193,9 @@ typedef struct {
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
 int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d); /* host-side query; <0 on error */
 int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d);        /* the fused data gradient (dg_w / dg_y) can run */
+/* 1 when d would run the 256-column tile of the MFMA-bound layers, which sums its pixel splits ONLY through `workspace`
+ * (sfk_conv_wgrad_workspace_bytes(d) bytes; without it the call still works, on the 128-column tile with atomics) */
+int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------------
  * sfk_stem_conv_fwd / sfk_stem_conv_wgrad -- the stem Conv3d (kt,7,7) stride (1,2,2) padding (kt/2,3,3), bias=False
@@ -457,6 +461,11 @@ typedef struct {
   int32_t igemm_tile256;      /* 3:    bit 0: 256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs;
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
   int32_t wgrad_target_gen;   /* 768:  ... of the register-staged filter-gradient kernels (0 = 1024)               */
+  int32_t wgrad_target_256;   /* 256:  workgroups (tiles x pixel splits, at most) of the 256-column filter-gradient tile: one per
+                                         CU; 0 = never use that tile                                                    */
+  int32_t wgrad_min_stages_256; /* 48: ... which runs only where a workgroup then still has this many 32-pixel stages        */
+  int32_t igemm_pipe;         /* 1:    software-pipelined main loop of the 256 x 256 implicit-GEMM tile (4-slot ring)      */
+  int32_t reserved0;
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

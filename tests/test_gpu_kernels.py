@@ -93,7 +93,10 @@ def test_conv_forward_and_stats(hip, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES[:9], ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in CONV_CASES[:9]])
+DGRAD_CASES = CONV_CASES[:9] + [CONV_CASES[-1], CONV_CASES[-2]]      # + the 256-output tile (pipelined main loop), plain and +=
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in DGRAD_CASES])
 def test_conv_data_gradient(hip, dtype, case):
     cin, cout, k, s, p, (n, t, h, w) = case
     gen = torch.Generator().manual_seed(7 + hash(case) % 1000)
@@ -154,6 +157,56 @@ def test_conv_filter_gradient(hip, dtype, case):
     hip.conv_wgrad(wp)(stream())
     torch.cuda.synchronize()
     assert rel_err(wp.dw.cpu(), dwc) < 5e-5
+
+
+WIDE_WGRAD_CASES = [
+    # cin, cout, k, s, p, (n, t, h, w)            the 256-column filter-gradient tile (MFMA-bound layers, workspace split sums)
+    (256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 8, 64, 64)),    # res4 conv_a at 1/4 width: 256 x 256 tile, 3 column tiles x 85 splits
+    (128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 100, 98)),   # res3 conv_b: 128 x 256 tile, 9 taps, 4.5 column tiles, ragged stages
+    (256, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 64, 63)),    # two co tiles
+]
+
+
+@pytest.mark.parametrize("case", WIDE_WGRAD_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}" for c in WIDE_WGRAD_CASES])
+def test_conv_filter_gradient_wide_tile_bf16(hip, case):
+    """conv_wgrad_dma_kernel<., ., false, 256>: the 256-column tile of the MFMA-bound filter gradients (one workgroup per CU,
+    pixel splits summed through the partial-tile workspace in split order).  Against the CPU restatement; two runs agree bit
+    for bit; without a workspace the call still gives the same gradient (128-column tile, atomics)."""
+    cin, cout, k, s, p, (n, t, h, w) = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(23 + cin + cout)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, k, s, p)
+    od = g.out_dims((t, h, w))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    dyc, dyg = fmap_pair(n, cout, *od, dtype, gen, ld=cout + 8, c_off=0)
+    base = torch.randn(cout * g.wtaps * cin, generator=gen)
+    dwc = base.clone()
+    emu.conv_wgrad(WgradPass(xc, dyc, g.s, list(wgrad_taps(g)), dwc, g.wtaps, cin, cout))(0)
+    wp = WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), None, g.wtaps, cin, cout)
+    wp.dw = base.clone().to(DEV)
+    assert hip.conv_wgrad_wants_workspace(wp)
+    need = hip.conv_wgrad_workspace_bytes(wp)
+    assert need > 0
+    outs = []
+    for _ in range(2):
+        wp.dw = base.clone().to(DEV)
+        wp.workspace = torch.full((need // 4 + 4,), float("nan"), device=DEV)
+        hip.conv_wgrad(wp)(stream())
+        torch.cuda.synchronize()
+        outs.append(wp.dw.cpu())
+    scale = float((dwc - base).abs().max())
+    assert float((outs[0] - dwc).abs().max()) < 2e-5 * scale + 1e-4, (float((outs[0] - dwc).abs().max()), scale)
+    assert torch.equal(outs[0], outs[1])
+    wp.dw = base.clone().to(DEV)                                   # no workspace: the 128-column tile with atomics
+    wp.workspace = None
+    hip.conv_wgrad(wp)(stream())
+    torch.cuda.synchronize()
+    assert float((wp.dw.cpu() - dwc).abs().max()) < 2e-5 * scale + 1e-4
+    small = WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), base.clone().to(DEV), g.wtaps, cin, cout)
+    small.x = FMap(xg.buf, 1, 1, 8, 8, cin, xg.ld, xg.c_off)      # a short pixel axis keeps the 128-column tile
+    small.dy = FMap(dyg.buf, 1, *g.out_dims((1, 8, 8)), cout, dyg.ld, dyg.c_off)
+    assert not hip.conv_wgrad_wants_workspace(small)
 
 
 def test_conv_rejects_bad_descriptors(hip):

@@ -15,6 +15,8 @@ LAYERS = {  # cin, cout, k, s, p, (t, h, w)     batch 32
     "b2": (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 56, 56)),
     "b3": (128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 28, 28)),
     "a2": (256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 56, 56)),
+    "a5": (2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (8, 7, 7)),
+    "b5": (512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 7, 7)),
     # fast pathway (T = 32)
     "fb2": (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 56, 56)),
     "fa2": (32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 56, 56)),
@@ -51,9 +53,9 @@ elif op == "dgrad":
 else:
     dw = torch.zeros(cout * g.wtaps * cin, device=dev)
     wp = WgradPass(x, y, g.s, list(wgrad_taps(g)), dw, g.wtaps, cin, cout)
-    need = be.conv_wgrad_workspace_bytes(wp)
-    if need > 0 and os.environ.get("SFK_WGWS", "1") != "0":
-        wp.workspace = torch.zeros(need // 4 + 4, device=dev)
+    # as the engine binds it: a workspace where the kernel wants one (the 256-column tile) or with SFK_WGWS=1 (deterministic sums)
+    if be.conv_wgrad_wants_workspace(wp) or os.environ.get("SFK_WGWS", "0") == "1":
+        wp.workspace = torch.zeros(be.conv_wgrad_workspace_bytes(wp) // 4 + 4, device=dev)
     runs = [be.conv_wgrad(wp)]
 st = torch.cuda.current_stream().cuda_stream
 for r in runs: r(st)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 10       # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 11       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -195,7 +195,9 @@ class _Tuning(C.Structure):
                 ("wgrad_target_8w", C.c_int32), ("wgrad_target_4w", C.c_int32), ("wgrad_use_workspace", C.c_int32),
                 ("wgrad_wide_co", C.c_int32), ("bn_parts", C.c_int32), ("nt_apply_mb", C.c_int32),
                 ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("igemm_pw_stream", C.c_int32),
-                ("pool_blocks", C.c_int64), ("igemm_tile256", C.c_int32), ("wgrad_target_gen", C.c_int32)]
+                ("pool_blocks", C.c_int64), ("igemm_tile256", C.c_int32), ("wgrad_target_gen", C.c_int32),
+                ("wgrad_target_256", C.c_int32), ("wgrad_min_stages_256", C.c_int32), ("igemm_pipe", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 # experiment knobs (tools/gpu_ab_env.sh): read HERE, once, on the host side of the boundary -- the library itself never
@@ -204,7 +206,8 @@ TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK
               "SFK_WGT8": "wgrad_target_8w", "SFK_WGT4": "wgrad_target_4w", "SFK_WGWS_LIB": "wgrad_use_workspace",
               "SFK_WG_WIDECO": "wgrad_wide_co", "SFK_BN_PARTS": "bn_parts", "SFK_NT_APPLY_MB": "nt_apply_mb",
               "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks",
-              "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_WGTG": "wgrad_target_gen"}
+              "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_WGTG": "wgrad_target_gen",
+              "SFK_WGT256": "wgrad_target_256", "SFK_WGMIN256": "wgrad_min_stages_256", "SFK_PIPE": "igemm_pipe"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)
@@ -222,6 +225,7 @@ SIGNATURES = {
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_conv_wgrad_dg_supported": [C.POINTER(_WgradDesc)],
+    "sfk_conv_wgrad_wants_workspace": [C.POINTER(_WgradDesc)],
     "sfk_stem_kp": [_I32, _I32],
     "sfk_stem_conv_tiles": [C.POINTER(_StemSrc), _P_FMAP],
     "sfk_stem_conv_fwd": [C.POINTER(_StemSrc), _PV, _P_FMAP, _PF, _PV],
@@ -439,6 +443,10 @@ class HipBackend:
     def conv_wgrad_dg_supported(self, p: WgradPass) -> bool:
         """the fused data gradient (p.dg_w, p.dg_y) can run with this filter-gradient pass"""
         return p.dg_w is not None and bool(self.lib.sfk_conv_wgrad_dg_supported(C.byref(self._wgrad_desc(p))))
+
+    def conv_wgrad_wants_workspace(self, p: WgradPass) -> bool:
+        """this pass would run the 256-column tile, which sums its pixel splits only through a workspace"""
+        return bool(self.lib.sfk_conv_wgrad_wants_workspace(C.byref(self._wgrad_desc(p))))
 
     def conv_wgrad_workspace_bytes(self, p: WgradPass) -> int:
         """bytes of scratch with which sfk_conv_wgrad sums its pixel splits without atomics (deterministically)"""

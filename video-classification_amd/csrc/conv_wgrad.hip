@@ -295,15 +295,21 @@ __device__ __forceinline__ void wg_swap16f(float& a, float& b) {
 // compute the data gradient  dg_y[pixel][ci] = sum_co dY[pixel][co] dg_w[ci][co]  of the stage's 32 pixels from the dY rows
 // the ring already holds -- dY is read from HBM once for both gradients.  Wave d of those four: pixels 16 (d & 1) .. +15,
 // channels 32 (d >> 1) .. +31; its 16 filter fragments (2 x 8 K-steps of 32 co) live in registers for the whole kernel.
-template <int TCO, int NW, bool DG = false>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_kernel(const WgradK k) {
-  constexpr int TCI = 128, R = MK;
+// TCI = 256 (256 x 256: 8 waves as 4 x 2 of 64 co x 128 columns, ONE workgroup per CU; 128 x 256: 4 waves as 2 x 2, two
+// workgroups per CU) for the MFMA-bound layers: twice the columns per staged dY row -- 32 B of LDS-DMA per MFMA cycle and CU instead of
+// 48 -- and 32 MFMAs per wave between two barriers instead of 16.  Its pixel splits ALWAYS go through the partial-tile
+// workspace (a 256 x 256 fp32 tile per split through the ~1.3 TB/s atomic path would cost more than the tile's MFMAs).
+template <int TCO, int NW, bool DG = false, int TCI = 128>
+__global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void conv_wgrad_dma_kernel(const WgradK k) {
+  constexpr int R = MK;
   constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
   constexpr int SO = LO / 16, SI = LI / 16;                 // 16-byte slots per row
   constexpr int NDO = R * LO / 1024 / NW, NDI = R * LI / 1024 / NW;   // DMA instructions per wave per stage
   constexpr int TILEO = R * LO, TILEI = R * LI, BUF = TILEO + TILEI;
-  constexpr int WCO = TCO / 64;                             // waves along co (each wave 64 co x 64 columns)
-  static_assert(NW == WCO * 2 && NDO >= 1 && NDI >= 1, "tile shape");
+  constexpr int WCO = TCO / 64;                             // waves along co (each wave 64 co)
+  constexpr int WCI = NW / WCO;                             // waves along the columns
+  constexpr int FI = TCI / WCI / 16;                        // 16-column fragments per wave (4 or 8)
+  static_assert(NW == WCO * WCI && (FI == 4 || FI == 8) && NDO >= 1 && NDI >= 1 && (!DG || TCI == 128), "tile shape");
   __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,10 +400,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
   // (see conv_igemm.hip ring_wait)
   auto ring_wait = [&]() {
-    static_assert(NDO + NDI >= 2 && NDO + NDI <= 4, "DMA count");
+    static_assert(NDO + NDI >= 2 && NDO + NDI <= 6, "DMA count");
     if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NDO + NDI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NDO + NDI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
 
@@ -455,21 +463,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
     }
   }
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][FI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // transpose-read addresses (loop-invariant): lane (g, q, p) reads row 8g+q (+4), channels c0+4p..+3
   const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
   const int frow = 8 * g + q, fs = wg_swz(frow);
-  int a_off[4], b_off[4];
+  int a_off[4], b_off[FI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_off[i] = frow * LO + (((wco * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
-    b_off[i] = TILEO + frow * LI + (((wci * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
-  }
+  for (int i = 0; i < 4; ++i) a_off[i] = frow * LO + (((wco * 8 + 2 * i + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
+#pragma unroll
+  for (int j = 0; j < FI; ++j) b_off[j] = TILEO + frow * LI + (((wci * (2 * FI) + 2 * j + (p4 >> 1)) ^ fs) << 4) + (p4 & 1) * 8;
   // The transposed reads go through inline asm: beside in-flight LDS-DMA, hipcc (ROCm 7.2) orders every
   // ds_read_tr intrinsic behind `s_waitcnt vmcnt(0)` -- it cannot tell which ring slot the read touches -- which drained
   // the look-ahead DMA before every stage (no overlap at all; the .s showed it).  As asm the reads are invisible to that
@@ -486,8 +493,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
   };
+  // column fragments in groups of 4: with FI = 8 the second group's reads are in flight while the first group's 16 MFMAs
+  // issue (and the 256 x 256 tile stays under its 256-VGPR cap: 128 accumulators + 3 x 16 fragment registers)
   auto compute = [&](int slot_base) __attribute__((always_inline)) {
-    bf16x8 a[4], b[4];
+    bf16x8 a[4], b[4], c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = rd(slot_base + a_off[i], LO);
 #pragma unroll
@@ -498,10 +507,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(b[j]));
+    if constexpr (FI == 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = rd(slot_base + b_off[4 + j], LI);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if constexpr (FI == 8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(c[j]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], c[j], acc[i][4 + j], 0, 0, 0);
+    }
   };
   dma(stage0, 0);
   dma(stage0 + 1, 1);
@@ -517,19 +539,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_ker
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (k.ws) {
-    float4* wp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * NW + wave) * 16) * 64 + lane;
+    float4* wp = k.ws + ((((int64_t)split_id * k.ntiles + tile_id) * NW + wave) * (4 * FI)) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        wp[(i * 4 + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      for (int j = 0; j < FI; ++j)
+        wp[(i * FI + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     return;
   }
   // D[row = co][col]: lane holds co = 4*(lane>>4) + r and column lane & 15
   const int l15 = lane & 15;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = cit * TCI + wci * 64 + 16 * j + l15;
+  for (int j = 0; j < FI; ++j) {
+    const int col = cit * TCI + wci * (16 * FI) + 16 * j + l15;
     uint32_t tap, ci;
     k.dcin.divmod((uint32_t)col, tap, ci);
     if (tap >= (uint32_t)k.ntaps) continue;
@@ -600,17 +622,19 @@ int launch_reduce(const WgradK& k, int splits, hipStream_t s) {
   return SFK_OK;
 }
 
-template <int TCO, int NW, bool DG = false>
+template <int TCO, int NW, bool DG = false, int TCI = 128>
 int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
-  k.citiles = (cols + 127) / 128;
+  constexpr int FI = TCI / (NW / (TCO / 64)) / 16;
+  k.citiles = (cols + TCI - 1) / TCI;
   k.nchunks = (k.M + MK - 1) / MK;
   const int base = cotiles * k.citiles;
   // pixel splits: one resident generation of workgroups (2 x 256 CUs for the 8-wave tile, 3 x 256 for the 4-wave one).
   // Every split adds a full copy of the tile to the fp32 atomic traffic (~1.3 TB/s chip-wide), so do not over-split.
   const int target8 = sfk_tune().wgrad_target_8w, target4 = sfk_tune().wgrad_target_4w;   // resident-block targets
-  int splits = ((NW == 8 ? target8 : target4) + base - 1) / base;
+  int splits = ((TCI == 256 ? sfk_tune().wgrad_target_256 : (NW == 8 ? target8 : target4)) + base - 1) / base;
+  if (TCI == 256) splits = sfk_tune().wgrad_target_256 / base;      // never more workgroups than the target: one per CU
   const int max_splits = (k.nchunks + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -618,12 +642,29 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   k.chunks_per_split = (k.nchunks + splits - 1) / splits;
   splits = (k.nchunks + k.chunks_per_split - 1) / k.chunks_per_split;
   k.ntiles = base;
-  if (dry) { *dry = (int64_t)splits * base * NW * 16 * 64 * 16; return SFK_OK; }
-  if (k.ws && (int64_t)splits * base * NW * 16 * 64 * 16 > d->workspace_bytes) k.ws = nullptr;
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
+  const int64_t need = (int64_t)splits * base * NW * (4 * FI) * 64 * 16;
+  if (dry) { *dry = need; return SFK_OK; }
+  if (k.ws && need > d->workspace_bytes) k.ws = nullptr;
+  if (TCI == 256 && !k.ws) return SFK_ERR_UNSUPPORTED;      // (the caller routes to the 128-column tile instead)
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG, TCI>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
-  if (k.ws) return launch_reduce<NW, TCO / 64, 4, 4>(k, splits, s);
+  if (k.ws) return launch_reduce<NW, TCO / 64, 4, FI>(k, splits, s);
   return SFK_OK;
+}
+
+// The 256-column tile (conv_wgrad_dma_kernel<., 8, false, 256>): MFMA-bound layers whose pixel axis is long enough that one
+// workgroup per CU still runs >= wgrad_min_stages_256 stages.  0: not a layer for it; else TCO (128 or 256).
+int wide_tile_co(const sfk_wgrad_desc* d, int M) {
+  if (!sfk_tune().wgrad_target_256 || d->x.dtype != SFK_BF16) return 0;
+  const int cols = d->ntaps * d->cin;
+  if (cols < 512 || d->cout < 128 || (d->cout > 128 && d->cout < 256)) return 0;
+  if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || sfk_fmap_bytes(&d->dy) >= 0x7FF00000ll) return 0;
+  const int tco = d->cout >= 256 ? 256 : 128;
+  const int base = ((d->cout + tco - 1) / tco) * ((cols + 255) / 256);
+  const int splits = sfk_tune().wgrad_target_256 / base;
+  if (splits < 1) return 0;
+  const int nchunks = (M + MK - 1) / MK;
+  return nchunks / splits >= sfk_tune().wgrad_min_stages_256 ? tco : 0;
 }
 
 // the fused data gradient rides on the 256 x 128 LDS-DMA tile with taps x cin = 64 (its second column half is idle)
@@ -701,6 +742,13 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   k.ws = use_ws ? reinterpret_cast<float4*>(d->workspace) : nullptr;
   k.dgw = nullptr; k.dgy = nullptr; k.dgld = 0; k.dgoff = 0;
   const int cols = d->ntaps * d->cin;
+  if constexpr (sizeof(T) == 2) {
+    const int wt = (!d->dg_w && (dry || k.ws)) ? wide_tile_co(d, k.M) : 0;
+    if (wt) {       // (no workspace / too small a one: SFK_ERR_UNSUPPORTED, and the 128-column tile below runs with atomics)
+      const int r = wt == 256 ? launch_dma<256, 8, false, 256>(k, d, s, dry) : launch_dma<128, 4, false, 256>(k, d, s, dry);
+      if (r != SFK_ERR_UNSUPPORTED) return r;
+    }
+  }
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
     if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s, dry);
@@ -743,6 +791,11 @@ extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
   int64_t bytes = 0;
   const int r = d->x.dtype == SFK_BF16 ? launch<bf16_t>(d, nullptr, &bytes) : launch<float>(d, nullptr, &bytes);
   return r != SFK_OK ? r : bytes;
+}
+
+extern "C" int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d) {
+  if (!d || validate(d) != SFK_OK || d->dg_w) return 0;
+  return wide_tile_co(d, (int)sfk_fmap_pixels(&d->dy)) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d) {

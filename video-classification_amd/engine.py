@@ -473,7 +473,8 @@ class Engine:
         if wl != home:
             pl.bwd.sync(wl, home)
             pl.bwd.cur_lane = wl
-        need = self.be.conv_wgrad_workspace_bytes(wp) if self.deterministic_wgrad else 0
+        wants = hasattr(self.be, "conv_wgrad_wants_workspace") and self.be.conv_wgrad_wants_workspace(wp)
+        need = self.be.conv_wgrad_workspace_bytes(wp) if (self.deterministic_wgrad or wants) else 0
         if need > 0:
             cap = self._wg_ws_need.get(wl, 0)
             self._wg_ws_need[wl] = max(cap, need)
