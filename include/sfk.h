@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped on EVERY change of a struct layout, a prototype or the meaning of an argument / tuning field.  include/sfk.abi holds
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
- * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 / igemm_pipe. */
+ * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256. */
 #define SFK_ABI_VERSION 11
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
@@ -464,8 +464,6 @@ typedef struct {
   int32_t wgrad_target_256;   /* 256:  workgroups (tiles x pixel splits, at most) of the 256-column filter-gradient tile: one per
                                          CU; 0 = never use that tile                                                    */
   int32_t wgrad_min_stages_256; /* 48: ... which runs only where a workgroup then still has this many 32-pixel stages        */
-  int32_t igemm_pipe;         /* 1:    software-pipelined main loop of the 256 x 256 implicit-GEMM tile (4-slot ring)      */
-  int32_t reserved0;
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

@@ -358,7 +358,7 @@ def run_k_steps(om, m, x, labels, k, lr, oracle_step=None, device="cpu"):
             continue
         uo, um = (a - before[kk]).flatten().double(), (b - before[kk]).flatten().double()
         cos = float(uo @ um / (uo.norm() * um.norm() + 1e-30))
-        upd[kk] = (cos, float(um.norm() / uo.norm().clamp_min(1e-30)), float((uo - um).abs().max()))
+        upd[kk] = (cos, float(um.norm() / uo.norm().clamp_min(1e-30)), float((uo - um).abs().max()), int(uo.numel()))
     return losses, upd
 
 
@@ -376,8 +376,11 @@ def assert_k_step_parity(losses, upd, lr, k, loss_rtol=2e-2, min_cos=0.8, med_co
         assert abs(lo - lm) <= tol * max(abs(lo), 1e-3), losses
     cosines = sorted(v[0] for v in upd.values())
     assert cosines[0] > min_cos and float(np.median(cosines)) > med_cos, (cosines[:5], float(np.median(cosines)))
-    for kk, (cos, ratio, mx) in upd.items():
-        assert 0.9 < ratio < 1.1, (kk, ratio)      # (measured up to 1.055 on a stem norm at depth 26, batch 8)
+    for kk, (cos, ratio, mx, numel) in upd.items():
+        # (measured up to 1.055 on a stem norm at depth 26, batch 8; an 8-element BatchNorm vector moves by 12 % when ONE
+        # of its sign-like Adam updates flips in one of the k steps: 0.883 seen on the fast stem's norm.bias)
+        lo_, hi_ = (0.9, 1.1) if numel > 64 else (0.75, 1.33)
+        assert lo_ < ratio < hi_, (kk, ratio, numel)
         assert mx <= 3.2 * lr * k * 2, (kk, mx)          # |m_hat / sqrt(v_hat)| <= (1-b1)/sqrt(1-b2) = 3.16 per step
 
 

@@ -92,10 +92,10 @@ def test_conv_forward_and_stats(hip, dtype, case):
     assert rel_err(sg.sum(0), sc.sum(0)) < 1e-4                     # fp32 partial sums even in bf16 mode
 
 
+DGRAD_CASES = CONV_CASES[:9] + [CONV_CASES[-1], CONV_CASES[-2]]      # + the 256-output-channel tile (plain and +=), 512 outputs
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-DGRAD_CASES = CONV_CASES[:9] + [CONV_CASES[-1], CONV_CASES[-2]]      # + the 256-output tile (pipelined main loop), plain and +=
-
-
 @pytest.mark.parametrize("case", DGRAD_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in DGRAD_CASES])
 def test_conv_data_gradient(hip, dtype, case):
     cin, cout, k, s, p, (n, t, h, w) = case
@@ -162,7 +162,7 @@ def test_conv_filter_gradient(hip, dtype, case):
 WIDE_WGRAD_CASES = [
     # cin, cout, k, s, p, (n, t, h, w)            the 256-column filter-gradient tile (MFMA-bound layers, workspace split sums)
     (256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 8, 64, 64)),    # res4 conv_a at 1/4 width: 256 x 256 tile, 3 column tiles x 85 splits
-    (128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 100, 98)),   # res3 conv_b: 128 x 256 tile, 9 taps, 4.5 column tiles, ragged stages
+    (64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 8, 100, 99)),    # 9 taps (two taps per column tile), 2.25 column tiles, ragged stages
     (256, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 64, 63)),    # two co tiles
 ]
 

@@ -196,8 +196,7 @@ class _Tuning(C.Structure):
                 ("wgrad_wide_co", C.c_int32), ("bn_parts", C.c_int32), ("nt_apply_mb", C.c_int32),
                 ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("igemm_pw_stream", C.c_int32),
                 ("pool_blocks", C.c_int64), ("igemm_tile256", C.c_int32), ("wgrad_target_gen", C.c_int32),
-                ("wgrad_target_256", C.c_int32), ("wgrad_min_stages_256", C.c_int32), ("igemm_pipe", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("wgrad_target_256", C.c_int32), ("wgrad_min_stages_256", C.c_int32)]
 
 
 # experiment knobs (tools/gpu_ab_env.sh): read HERE, once, on the host side of the boundary -- the library itself never
@@ -207,7 +206,7 @@ TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK
               "SFK_WG_WIDECO": "wgrad_wide_co", "SFK_BN_PARTS": "bn_parts", "SFK_NT_APPLY_MB": "nt_apply_mb",
               "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks",
               "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_WGTG": "wgrad_target_gen",
-              "SFK_WGT256": "wgrad_target_256", "SFK_WGMIN256": "wgrad_min_stages_256", "SFK_PIPE": "igemm_pipe"}
+              "SFK_WGT256": "wgrad_target_256", "SFK_WGMIN256": "wgrad_min_stages_256"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)

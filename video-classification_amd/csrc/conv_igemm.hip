@@ -12,7 +12,6 @@
 //   f32 : v_mfma_f32_16x16x4_f32 x8 per K-step (bit-exact fp32 fma chain) -- the parity precision
 #include "sfk_common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -826,14 +825,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // BMS: pixel rows a tile COMPUTES (= the tile stride over M); BM rows are staged.  BMS < BM (224 of 256, waves as 2 x 4 with
 // 7 row fragments each) exists for the tile-count arithmetic: M = 50,176 (res4) is 196 tiles of 256 rows -- 0.77 of one
 // generation on 256 CUs -- but 224 tiles of 224 rows; the 32 extra staged rows cost L2 -> LDS traffic an MFMA-bound layer has.
-// PIPE (the 256 x 256 tile, one workgroup per CU): the main loop software-pipelined INSIDE every wave.  The plain loop is
-// {DMA issue, 12 fragment reads, wait, 32 MFMAs, barrier}: after every barrier all eight waves read LDS at once and the
-// matrix pipes idle until the first fragments are back.  Here a step's fragments are already in registers when its first
-// MFMA issues: the operand with 4 fragments per wave (S) and the first half of the other one (P0) are read from ring slot
-// it+1 while step it's SECOND 16 MFMAs run, the second half (P1) from slot it while its first 16 run -- 64 fragment registers
-// instead of 48, a 4-slot ring (slot it+1 must have landed one step earlier than the plain loop needs it; the DMA runs
-// three steps ahead), still one barrier per 32-deep K-step.
-template <int BM, int BN, int WM, int WN, int EPI = 0, int BMS = BM, int PIPE = 0>
+template <int BM, int BN, int WM, int WN, int EPI = 0, int BMS = BM>
 __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 3))) void conv_igemm_dma_kernel(const ConvK k) {
   using T = bf16_t;
   using TL = Tile<bf16_t>;
@@ -845,8 +837,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
   constexpr int XI = BM / (16 * NW), WI = WROWS / (16 * NW);   // DMA wave-instructions per wave per K-step
   constexpr int BUF = (BM + WROWS) * ROWB;
   constexpr int RED = WM * BN * 2 * 4;
-  constexpr int NSLOT = PIPE ? 4 : 3;
-  constexpr int SM = NSLOT * BUF > RED ? NSLOT * BUF : RED;
+  constexpr int SM = 3 * BUF > RED ? 3 * BUF : RED;
   constexpr int TAB = 32;   // ints per table
   static_assert((NW == 4 || NW == 8) && BM % (16 * NW) == 0, "tile shape");
   // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt(0) before every fragment read): ring | tables
@@ -1012,123 +1003,6 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
     __builtin_amdgcn_s_barrier();
   };
 
-  if constexpr (PIPE) {
-    static_assert(BN == 256 && (FM == 4 || FN == 4), "pipelined loop: the 256 x 256 tile");
-    constexpr bool SPLIT_A = FN > FM;               // which operand is split in halves: the filter (co) or the pixel fragments
-    constexpr int NS = SPLIT_A ? FM : FN, NP = SPLIT_A ? FN : FM, NP1 = NP - 4;
-    static_assert(NS == 4 && NP1 >= 1 && NP1 <= 4, "fragment split");
-    TL::frag sA[NS], sB[NS], p0[4], p1[NP1];
-    // The fragment reads are inline asm with hand-counted waits: hipcc's own counter puts `lgkmcnt(0)` in front of the first
-    // MFMA of a step whatever is in flight behind the reads it needs (the loop's back edge merges its bookkeeping), which
-    // would make every step wait for the prefetch it has just issued.
-    // ring slot s of fragment address ad: base register ad (slots 0, 1) or ad + 2 BUF (slots 2, 3) plus the instruction's
-    // 16-bit offset field (0 or BUF) -- 24 address registers; one pre-added address per (fragment, slot) would be 48
-    static_assert(BUF == 32768, "slot bases as ds_read offset immediates");
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    uint32_t a_lo[FN], a_hi[FN], b_lo[FM], b_hi[FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) { a_lo[i] = lds0 + (uint32_t)a_off[i]; a_hi[i] = a_lo[i] + 2u * BUF; }
-#pragma unroll
-    for (int j = 0; j < FM; ++j) { b_lo[j] = lds0 + (uint32_t)b_off[j]; b_hi[j] = b_lo[j] + 2u * BUF; }
-    auto RD = [&](TL::frag& f, uint32_t lo, uint32_t hi, auto slot) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot)::value;
-      if constexpr ((SL & 1) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(SL < 2 ? lo : hi));
-      else asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(f) : "v"(SL < 2 ? lo : hi));
-    };
-    auto ldS = [&](TL::frag (&sx)[NS], auto slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        if constexpr (SPLIT_A) RD(sx[q], b_lo[q], b_hi[q], slot);
-        else RD(sx[q], a_lo[q], a_hi[q], slot);
-      }
-    };
-    auto ldP0 = [&](auto slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if constexpr (SPLIT_A) RD(p0[q], a_lo[q], a_hi[q], slot);
-        else RD(p0[q], b_lo[q], b_hi[q], slot);
-      }
-    };
-    auto ldP1 = [&](auto slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NP1; ++q) {
-        if constexpr (SPLIT_A) RD(p1[q], a_lo[4 + q], a_hi[4 + q], slot);
-        else RD(p1[q], b_lo[4 + q], b_hi[4 + q], slot);
-      }
-    };
-    // uses of asm-read registers stay BELOW the wait that covers them (an MFMA touches no memory, so a "memory" clobber
-    // does not order it: guide rule 18)
-    auto pinS = [&](TL::frag (&sx)[NS]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(sx[q]));
-    };
-    auto pinP0 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(p0[q]));
-    };
-    auto pinP1 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NP1; ++q) asm volatile("" : "+v"(p1[q]));
-    };
-    auto mm0 = [&](const TL::frag (&sx)[NS]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-          if constexpr (SPLIT_A) TL::mma(acc[q][r], p0[q], sx[r]);
-          else TL::mma(acc[r][q], sx[r], p0[q]);
-        }
-    };
-    auto mm1 = [&](const TL::frag (&sx)[NS]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < NP1; ++q)
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-          if constexpr (SPLIT_A) TL::mma(acc[4 + q][r], p1[q], sx[r]);
-          else TL::mma(acc[r][4 + q], sx[r], p1[q]);
-        }
-    };
-    // top of step `it` (ring_wait): slot it+1 has landed for every wave (this wave's DMAs but the newest XI+WI are done, then
-    // the barrier); every fragment read issued so far has returned (lgkmcnt(0): the reads of S and P0 for THIS step, issued
-    // half a step ago) -- so every wave is done with slot it-1, which the DMA of step it+3 overwrites next.
-    // Then: P1 reads (slot it) fly during the first 16 MFMAs; S' / P0' reads (slot it+1) during the second 16, which wait
-    // only for P1 -- lgkmcnt(8) = the eight newer reads stay in flight.
-#define SFK_PIPE_STEP(SLOT, SCUR, SNEXT)                                                \
-    ring_wait();                                                                        \
-    pinS(SCUR); pinP0();                                                                \
-    dma(((SLOT) + 3) & 3, it + 3);                                                      \
-    ldP1(std::integral_constant<int, (SLOT)>{});                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    mm0(SCUR);                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    ldS(SNEXT, std::integral_constant<int, (((SLOT) + 1) & 3)>{});                      \
-    ldP0(std::integral_constant<int, (((SLOT) + 1) & 3)>{});                            \
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                  \
-    pinP1();                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    mm1(SCUR);                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
-    dma(0, 0);
-    dma(1, 1);
-    dma(2, 2);
-    if constexpr (XI + WI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // slot 0 has landed (two steps stay in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ldS(sA, std::integral_constant<int, 0>{});
-    ldP0(std::integral_constant<int, 0>{});
-    for (int it = 0;;) {
-      SFK_PIPE_STEP(0, sA, sB)
-      if (++it >= k.KC) break;
-      SFK_PIPE_STEP(1, sB, sA)
-      if (++it >= k.KC) break;
-      SFK_PIPE_STEP(2, sA, sB)
-      if (++it >= k.KC) break;
-      SFK_PIPE_STEP(3, sB, sA)
-      if (++it >= k.KC) break;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the last step's (unused) look-ahead reads
-#undef SFK_PIPE_STEP
-  } else {
   // 3-slot ring, unrolled so that slot addresses are immediates.  Invariant at the top of a sub-step that computes
   // slot c: c has landed for every wave (barrier); the DMAs of the next step are in flight.  Issue the step after
   // next into the slot the previous step vacated, run this step, wait until only this wave's newest XI+WI DMAs are
@@ -1143,7 +1017,6 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
     if (++it >= k.KC) break;
     dma(1, it + 2); compute(2 * BUF); ring_wait();
     if (++it >= k.KC) break;
-  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (all-out-of-range) look-ahead DMAs before LDS is reused
   __syncthreads();
@@ -1311,13 +1184,8 @@ int validate(const sfk_conv_desc* d) {
 
 int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
   if (bn == 256) {
-    if (sfk_tune().igemm_pipe) {       // software-pipelined main loop (4-slot ring, fragments one half-step ahead)
-      if (bm == 224) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 2, 4, 0, 224, 1>), grid, dim3(512), 0, s, k);
-      else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2, 0, 256, 1>), grid, dim3(512), 0, s, k);
-    } else {
-      if (bm == 224) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 2, 4, 0, 224>), grid, dim3(512), 0, s, k);
-      else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, k);
-    }
+    if (bm == 224) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 2, 4, 0, 224>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 256, 4, 2>), grid, dim3(512), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }

@@ -295,8 +295,7 @@ __device__ __forceinline__ void wg_swap16f(float& a, float& b) {
 // compute the data gradient  dg_y[pixel][ci] = sum_co dY[pixel][co] dg_w[ci][co]  of the stage's 32 pixels from the dY rows
 // the ring already holds -- dY is read from HBM once for both gradients.  Wave d of those four: pixels 16 (d & 1) .. +15,
 // channels 32 (d >> 1) .. +31; its 16 filter fragments (2 x 8 K-steps of 32 co) live in registers for the whole kernel.
-// TCI = 256 (256 x 256: 8 waves as 4 x 2 of 64 co x 128 columns, ONE workgroup per CU; 128 x 256: 4 waves as 2 x 2, two
-// workgroups per CU) for the MFMA-bound layers: twice the columns per staged dY row -- 32 B of LDS-DMA per MFMA cycle and CU instead of
+// TCI = 256 (256 x 256: 8 waves as 4 x 2 of 64 co x 128 columns, ONE workgroup per CU) for the MFMA-bound layers: twice the columns per staged dY row -- 32 B of LDS-DMA per MFMA cycle and CU instead of
 // 48 -- and 32 MFMAs per wave between two barriers instead of 16.  Its pixel splits ALWAYS go through the partial-tile
 // workspace (a 256 x 256 fp32 tile per split through the ~1.3 TB/s atomic path would cost more than the tile's MFMAs).
 template <int TCO, int NW, bool DG = false, int TCI = 128>
@@ -653,13 +652,15 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
 }
 
 // The 256-column tile (conv_wgrad_dma_kernel<., 8, false, 256>): MFMA-bound layers whose pixel axis is long enough that one
-// workgroup per CU still runs >= wgrad_min_stages_256 stages.  0: not a layer for it; else TCO (128 or 256).
+// workgroup per CU still runs >= wgrad_min_stages_256 stages.  0: not a layer for it; else the tile's co extent (256).
 int wide_tile_co(const sfk_wgrad_desc* d, int M) {
   if (!sfk_tune().wgrad_target_256 || d->x.dtype != SFK_BF16) return 0;
   const int cols = d->ntaps * d->cin;
-  if (cols < 512 || d->cout < 128 || (d->cout > 128 && d->cout < 256)) return 0;
+  // (a 128 x 256 variant -- 4 waves of 64 x 128, two workgroups per CU -- was measured on slow res3's 3 x 3 layers: 162 vs 157 us
+  // for the 128-column tile, so layers with fewer than 256 output channels keep that one)
+  if (cols < 512 || d->cout < 256) return 0;
   if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || sfk_fmap_bytes(&d->dy) >= 0x7FF00000ll) return 0;
-  const int tco = d->cout >= 256 ? 256 : 128;
+  const int tco = 256;
   const int base = ((d->cout + tco - 1) / tco) * ((cols + 255) / 256);
   const int splits = sfk_tune().wgrad_target_256 / base;
   if (splits < 1) return 0;
@@ -745,7 +746,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   if constexpr (sizeof(T) == 2) {
     const int wt = (!d->dg_w && (dry || k.ws)) ? wide_tile_co(d, k.M) : 0;
     if (wt) {       // (no workspace / too small a one: SFK_ERR_UNSUPPORTED, and the 128-column tile below runs with atomics)
-      const int r = wt == 256 ? launch_dma<256, 8, false, 256>(k, d, s, dry) : launch_dma<128, 4, false, 256>(k, d, s, dry);
+      const int r = launch_dma<256, 8, false, 256>(k, d, s, dry);
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
   }

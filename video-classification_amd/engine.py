@@ -145,13 +145,6 @@ class Engine:
         # both pathways' filter gradients on ONE lane (lane 2): three compute streams, so that the collective's stream of a
         # world > 1 step is the fourth hardware queue (dist.GradReducer; single-rank: 1078 vs 1077 clips/s, neutral)
         self.wgrad_one_lane = os.environ.get("SFK_WGRAD_LANES", "1") == "2"
-        # Filter gradients feed nothing but Adam, and every buffer they read has its own allocation, so they may run LATER than
-        # the point where their operands exist: the slow pathway's res4 / res5 filter gradients are MFMA-bound like the data
-        # gradients the trunk runs at that time, while res3 / res2's backward is HBM-bound.  wgrad_defer = d holds the filter
-        # gradients of slow stage si >= 2 back until the trunk starts the backward of stage si - d (0 = as soon as possible).
-        self.wgrad_defer = int(os.environ.get("SFK_WG_DEFER", "0"))
-        self._wg_deferred: Dict[int, list] = {}
-        self._wg_stage = None             # slow-pathway stage whose backward is being scheduled (None: do not defer)
         self.relu_bits = os.environ.get("SFK_RELU_BITS", "1") != "0"       # block-output ReLU masks kept as bitmaps
         # ... and applied by the data-gradient pass that finishes the gradient of an identity-shortcut block's output
         # (sfk_conv_desc.out_relu_bits): that block's BatchNorm backward then reads dz as it is, no mask, no rewrite
@@ -466,10 +459,6 @@ class Engine:
         # leaves on the chip; the lane waits for the producer of dy, everything joins before the optimiser.
         home = pl.bwd.cur_lane
         wl = (2 if self.wgrad_one_lane else home + 2) if self.wgrad_lanes else home
-        if (self.wgrad_defer > 0 and self.wgrad_lanes and home == 0 and self._wg_stage is not None and self._wg_stage >= 2
-                and not getattr(self, "_wg_flushing", False)):
-            self._wg_deferred.setdefault(self._wg_stage, []).append((rec, dy))
-            return
         if wl != home:
             pl.bwd.sync(wl, home)
             pl.bwd.cur_lane = wl
@@ -485,18 +474,6 @@ class Engine:
                       bytes=float(esz * (rec.x.pixels * L.eg.cin + dy.pixels * L.eg.cout) + 4 * L.w_numel))
         pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
         pl.bwd.cur_lane = home
-
-    def _flush_deferred_wgrads(self, pl: Plan, upto_stage: int):
-        """emit the held-back filter gradients of the slow stages >= upto_stage (their lane waits for the trunk as it is now)"""
-        self._wg_flushing = True
-        keep = pl.bwd.cur_lane
-        pl.bwd.cur_lane = 0
-        for si in sorted(self._wg_deferred, reverse=True):
-            if si >= upto_stage:
-                for rec, dy in self._wg_deferred.pop(si):
-                    self._wgrad(pl, rec, dy)
-        pl.bwd.cur_lane = keep
-        self._wg_flushing = False
 
     def _dgrad(self, pl: Plan, rec: _UnitRec, dy: FMap, dx: FMap, accumulate: bool, fuse=None, out_bits=None,
                out_sum_tag=None):
@@ -895,7 +872,6 @@ class Engine:
         be, spec, W = self.be, self.spec, self.wiring
         pl = Plan()
         self._wg_ws_need, self._wg_pending = {}, []
-        self._wg_deferred, self._wg_stage = {}, None
         self._tail_zero_layout(train)
         NP = spec.pathways                              # 2: SlowFast; 1: the single-pathway `res3d` network (slow_r50)
         n = x_slow.shape[0]
@@ -1032,11 +1008,7 @@ class Engine:
         for si in range(3, -1, -1):
             # slow pathway of this stage: d_xs is the gradient of its last block's output
             B_.cur_lane = 0
-            if self.wgrad_defer > 0:
-                self._flush_deferred_wgrads(pl, si + self.wgrad_defer)
-            self._wg_stage = si
             d = self._stage_bwd(pl, stage_recs[si][0], d_xs)
-            self._wg_stage = None
             d_cat = d                                   # gradient of the (concatenated) slow input of this stage
             if NP == 2:
                 B_.cur_lane = 1
@@ -1047,8 +1019,6 @@ class Engine:
                 self._fusion_bwd(pl, si, fusion_recs[si], d_cat.channels(c_prev, d_cat.c - c_prev), d_xf)
             d_xs = d_cat.channels(0, c_prev)
         B_.cur_lane = 0
-        if self.wgrad_defer > 0:
-            self._flush_deferred_wgrads(pl, 0)
         self._stem_bwd(pl, 0, stem_recs[0], d_xs)
         if NP == 2:
             B_.cur_lane = 1
