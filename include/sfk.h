@@ -461,8 +461,10 @@ typedef struct {
   int32_t igemm_tile256;      /* 3:    bit 0: 256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs;
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
   int32_t wgrad_target_gen;   /* 768:  ... of the register-staged filter-gradient kernels (0 = 1024)               */
-  int32_t wgrad_target_256;   /* 256:  workgroups (tiles x pixel splits, at most) of the 256-column filter-gradient tile: one per
-                                         CU; 0 = never use that tile                                                    */
+  int32_t wgrad_target_256;   /* 0:    workgroups (tiles x pixel splits, at most; 256 = one per CU) of the 256-column
+                                         filter-gradient tile; 0 = never use that tile.  Off by default: alone on the chip it is
+                                         25..29 % faster on res4 (684 vs 532 TFLOP/s), but a workgroup owns its whole CU (96 KB of
+                                         LDS, 8 x 256 VGPRs), so beside the trunk's kernels the STEP loses 1.4 %             */
   int32_t wgrad_min_stages_256; /* 48: ... which runs only where a workgroup then still has this many 32-pixel stages        */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */

@@ -94,7 +94,8 @@ def test_mini_bf16_forward_and_gradients(ref_style):
         cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
     # bf16 storage (8 mantissa bits) flips many ReLU/arg-max decisions of this tiny batch; fp32 self-noise is already 2e-2
     print("mini bf16 gradient cosines: median", np.median(cos), "min", min(cos))
-    assert np.median(cos) > 0.9 and min(cos) > 0.7, (np.median(cos), min(cos))
+    # measured on MI355X (round 3): median 0.952 / 0.941, worst tensor 0.913 / 0.820 (ref / canonical)
+    assert np.median(cos) > 0.92 and min(cos) > 0.75, (np.median(cos), min(cos))
 
 
 def test_reference_geometry_forward_fp32():
@@ -381,7 +382,8 @@ def test_train_step_two_steps_bf16_vs_fp32_oracle(ref_style):
     # Adam's update is sign-like: a cosine of 0.82 = 9 % of the elements (those with near-zero gradients) changed sign
     # under bf16 storage -- measured median 0.82..0.84, worst 0.49; a wrong update (stale filter copy, wrong step count)
     # is caught exactly by run_k_steps' check_filter_copies / adam_step asserts, which run here on the bf16 refresh path
-    assert np.median(cos) > 0.75 and cos[0] > 0.35, (cos[:5], np.median(cos))
+    # (round 3, MI355X: median 0.826 / 0.831, worst 0.462 / 0.521)
+    assert np.median(cos) > 0.78 and cos[0] > 0.40, (cos[:5], np.median(cos))
     assert all(0.8 < v[1] < 1.25 for v in upd.values())
 
 
@@ -442,57 +444,114 @@ def test_metric_geometry_forward_fp32():
     assert rel_err(got, want) < FWD_TOL_F32
 
 
+class _RoundBF16(torch.autograd.Function):
+    """y = bf16(x) forward, bf16(g) backward: what STORING a tensor and its gradient in bf16 does to them"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _emulate_bf16_storage(model):
+    """the fp32 oracle with every conv / BatchNorm / ReLU / pool output (and its gradient) rounded to bf16: the yardstick of
+    what ANY correct bf16 implementation of the step looks like against the fp32 one"""
+    return [mod.register_forward_hook(lambda m_, inp, out: _RoundBF16.apply(out)) for mod in model.modules()
+            if isinstance(mod, (torch.nn.Conv3d, torch.nn.BatchNorm3d, torch.nn.ReLU, torch.nn.MaxPool3d))]
+
+
+def _mild_state(om, seed):
+    """A parameter state in which the residual network does not amplify: the reference init (Kaiming filters, gamma 1) with the
+    block-final gammas in [0.1, 0.3] (init: 0), every other gamma in [0.75, 1.25], betas ~ N(0, 0.1), seeded non-trivial running
+    statistics.  With randomize()'s gammas in [0.5, 1.5] on all 32 residual branches the depth-50 model is chaotic: the fp32
+    oracle WITH bf16 storage emulated keeps a gradient cosine of 0.23 against itself without (measured, tools/probe/bf16_parity.py)
+    -- no implementation can be told from another there."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in om.state_dict().items():
+            if k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+            elif "norm_c.weight" in k:
+                v.copy_(torch.rand(v.shape, generator=g) * 0.2 + 0.1)
+            elif ".norm" in k and k.endswith("weight"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.75)
+            elif ".norm" in k and k.endswith("bias"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif v.dim() == 5:                             # the 110 Conv3d filters: values both precisions hold exactly
+                v.copy_(v.to(torch.bfloat16).float())
+
+
 def test_metric_geometry_train_step_bf16_vs_fp32_oracle():
     """The benchmark's OWN numerics: canonical SlowFast-R50 8x8 (depth 50, 400 classes), 3 x 32 x 224^2 clips, bf16, train mode,
     through the fused TrainStep bench.py times (LDS-DMA tiles, streaming pointwise kernels, fused block tails, dg_w / dg_y filter
     gradients -- all bf16-only code the fp32 parity tests never run) against the fp32 oracle's forward / cross-entropy / backward
-    (/root/reference/train.py:225-231) on the SAME clips, weights (bf16-representable, so the only difference is the
-    precision activations and gradients are stored in) and dropout mask.  N = 2: one oracle step at this size is seconds.
-    Bounds = what was measured on MI355X (printed below) plus margin; a wrong tile, a dropped K-step or a mis-addressed slab at
-    M = 802,816 moves the tensors it touches by O(1)."""
+    (/root/reference/train.py:225-231) on the SAME clips, weights (bf16-representable filters: the only difference is the
+    precision activations and gradients are STORED in) and dropout mask.  N = 2: one oracle step at this size takes seconds.
+
+    Yardstick: the oracle itself with bf16 storage emulated (_emulate_bf16_storage).  Measured on MI355X (round 3, N = 2):
+        engine bf16 vs fp32 oracle    logits 1.9e-3, loss 6.1328 vs 6.1323, running var 2.0e-3,
+                                      gradient cosine per tensor: median 0.9285, 10th percentile 0.9025, worst 0.785
+        bf16-storage oracle vs same   logits 2.3e-3, cosine median 0.9257, 10th percentile 0.894, worst 0.436
+        engine fp32 vs fp32 oracle    cosine median 1.0000, worst 0.9999 (test_metric_geometry_... fp32 forward, the probe)
+    i.e. the engine loses what bf16 storage costs and nothing else.  A wrong tile, a dropped K-step or a mis-addressed slab at
+    M = 802,816 moves the tensors it touches -- and everything upstream of them -- by O(1)."""
     from video_classification_amd.train import TrainStep
     torch.manual_seed(0)
     om = o.canonical_slowfast_8x8(400)
-    randomize(om, 3)
-    with torch.no_grad():                                  # weights both sides can hold exactly
-        for k, v in om.state_dict().items():
-            if v.dim() == 5:                               # the 110 Conv3d filters (BatchNorm / Linear parameters stay fp32)
-                v.copy_(v.to(torch.bfloat16).float())
+    _mild_state(om, 3)
+    sd0 = {k: v.clone() for k, v in om.state_dict().items()}
     m = SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, backend=hip_backend())
-    m.load_state_dict(om.state_dict(), strict=True)
+    m.load_state_dict(sd0, strict=True)
     frames = torch.randn(2, 3, 32, 224, 224, generator=torch.Generator().manual_seed(21)).to(torch.bfloat16)
     labels = torch.tensor([7, 311])
+    x_cpu = o.pack_pathway(frames.float())
     eng = m.engine
     m.train()
-    y_o, loss_o = oracle_train_step_with_engine_mask(om, eng, o.pack_pathway(frames.float()), labels)
+    y_o, loss_o = oracle_train_step_with_engine_mask(om, eng, x_cpu, labels)
+    ref = {k: p.grad.clone() for k, p in om.named_parameters()}
+    osd = {k: v.clone() for k, v in om.state_dict().items()}
+    # the yardstick: same step, same dropout mask, bf16 storage emulated inside the oracle
+    om.load_state_dict(sd0)
+    hooks = _emulate_bf16_storage(om)
+    y_e, _ = oracle_train_step_with_engine_mask(om, eng, x_cpu, labels)
+    for h in hooks:
+        h.remove()
+    emu = {k: p.grad.clone() for k, p in om.named_parameters()}
+
     step = TrainStep(eng, lr=0.0, use_graph=False)                     # lr 0: the arena G is the result, P stays
     fd = frames.to(DEV)
     idx = pack_pathway_index(32, 4, DEV)
     loss_m = float(step(fd, fd, labels.to(DEV), slow_t_index=idx))
     torch.cuda.synchronize()
     y_m = eng._plan_for(fd, fd, idx, True).logits.float().cpu()
-    fwd = rel_err(y_m, y_o)
     gsd = engine_grads_as_state_dict(eng)
-    rows = []
-    for k, p in om.named_parameters():
-        assert p.grad is not None, k
-        a, b = gsd[k].cpu().flatten().double(), p.grad.flatten().double()
-        rows.append((float(a @ b / (a.norm() * b.norm() + 1e-30)), float(a.norm() / (b.norm() + 1e-30)), k, a.numel()))
-    rows.sort()
-    cos = np.array([r[0] for r in rows])
-    wide = np.array([r[0] for r in rows if r[3] >= 4096])               # filters (not the 8..2048-element BatchNorm vectors)
-    osd = om.state_dict()
+
+    def cosines(grads):
+        rows = []
+        for k, r in ref.items():
+            a, b = grads[k].cpu().flatten().double(), r.flatten().double()
+            rows.append((float(a @ b / (a.norm() * b.norm() + 1e-30)), float(a.norm() / (b.norm() + 1e-30)), k))
+        return sorted(rows)
+    rows, rows_e = cosines(gsd), cosines(emu)
+    cos, cos_e = np.array([r[0] for r in rows]), np.array([r[0] for r in rows_e])
+    fwd, fwd_e = rel_err(y_m, y_o), rel_err(y_e, y_o)
     rm = max(rel_err(L.rm.cpu(), osd[L.cb.norm_key + ".running_mean"]) for L in eng.layers)
     rv = max(rel_err(L.rv.cpu(), osd[L.cb.norm_key + ".running_var"]) for L in eng.layers)
-    print(f"bf16 depth-50 224^2 N=2: logits rel err {fwd:.3e}, loss {loss_m:.4f} vs {float(loss_o):.4f}, running mean/var "
-          f"{rm:.2e}/{rv:.2e}; gradient cosine median {np.median(cos):.4f} (filters {np.median(wide):.4f}), worst five "
-          f"{[(round(r[0], 3), r[2]) for r in rows[:5]]}, norm ratio range {min(r[1] for r in rows):.3f}..{max(r[1] for r in rows):.3f}")
-    assert fwd < 5e-2, fwd                                             # 110 layers of bf16 storage
-    assert abs(loss_m - float(loss_o)) < 0.02 * float(loss_o)
+    print(f"bf16 depth-50 224^2 N=2: logits {fwd:.2e} (bf16-storage oracle {fwd_e:.2e}), loss {loss_m:.4f} vs {float(loss_o):.4f}, "
+          f"running mean / var {rm:.2e} / {rv:.2e}; gradient cosine median {np.median(cos):.4f} p10 {np.percentile(cos, 10):.4f} "
+          f"worst {rows[0][:3]} | bf16-storage oracle: median {np.median(cos_e):.4f} p10 {np.percentile(cos_e, 10):.4f} worst {rows_e[0][:3]}")
+    assert fwd < 1e-2 and fwd < 3.0 * fwd_e + 1e-3, (fwd, fwd_e)
+    assert abs(loss_m - float(loss_o)) < 5e-3 * float(loss_o)
     assert rm < 1e-2 and rv < 1e-2, (rm, rv)
-    assert np.median(cos) > 0.98 and np.median(wide) > 0.98, (np.median(cos), np.median(wide))
-    assert cos.min() > 0.9, rows[:5]
-    assert all(0.8 < r[1] < 1.25 for r in rows), [r for r in rows if not 0.8 < r[1] < 1.25][:5]
+    assert np.median(cos) > 0.90 and np.percentile(cos, 10) > 0.85 and cos.min() > 0.6, (np.median(cos), rows[:5])
+    # ... and no worse than bf16 storage makes the oracle itself
+    assert np.median(cos) > np.median(cos_e) - 0.03 and np.percentile(cos, 10) > np.percentile(cos_e, 10) - 0.05
+    assert all(0.4 < r[1] < 2.0 for r in rows), [r for r in rows if not 0.4 < r[1] < 2.0][:5]
 
 
 @pytest.mark.parametrize("size,head", [(192, (17, 5, 5)), (64, (17, 1, 1))], ids=["HTAH-192", "Hand-64"])

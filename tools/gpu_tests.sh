@@ -12,4 +12,7 @@ for f in $FILES; do
   grep -E "^(FAILED|ERROR)|worst" gpurun_out/$name.log | head -40 | tee -a gpurun_out/tests_summary.log
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/tests_summary.log; exit $rc; fi
 done
+# opt-in kernels: the 256-column filter-gradient tile (tuning knob off by default)
+SFK_WGT256=256 timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -p no:cacheprovider -k "wide_tile or filter_gradient" > gpurun_out/test_gpu_kernels_wgt256.log 2>&1
+echo "test_gpu_kernels (SFK_WGT256=256) exit $?: $(tail -n 1 gpurun_out/test_gpu_kernels_wgt256.log)" | tee -a gpurun_out/tests_summary.log
 exit 0

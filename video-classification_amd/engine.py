@@ -141,6 +141,9 @@ class Engine:
         # BatchNorm-backward reduce folded into the dgrad epilogues (sfk_conv_desc.bnb): removes 3.3 ms of reduce kernels,
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
+        # diagnostic: kernel classes (OpList meta kinds, comma separated) that the lane scheduler SKIPS -- what does the step time
+        # owe to one class?  (tools/gpu_ablate.sh; results are garbage with anything skipped)
+        self._ablate_kinds = frozenset(k for k in os.environ.get("SFK_ABLATE", "").split(",") if k)
         self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
         # both pathways' filter gradients on ONE lane (lane 2): three compute streams, so that the collective's stream of a
         # world > 1 step is the fourth hardware queue (dist.GradReducer; single-rank: 1078 vs 1077 clips/s, neutral)
@@ -1105,8 +1108,11 @@ class Engine:
             return self._run(ops[begin:end], self._stream())
         streams = self.lane_streams()
         handles = [s.cuda_stream for s in streams]
+        skip = self._ablate_kinds
         for i in range(begin, end):
             op, lane = ops[i], ops.lane[i]
+            if skip and ops.meta[i] is not None and ops.meta[i].get("kind") in skip:
+                continue                 # TIMING ABLATION ONLY (SFK_ABLATE): the step's results are wrong
             if isinstance(op, Wait):
                 ev = torch.cuda.Event()
                 ev.record(streams[op.on])
