@@ -642,9 +642,10 @@ def test_conv_fused_bn_backward_reduce(hip, case):
     yb = dA()
     cp = ConvPass(xg, yb, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wgt, g.wtaps, cin, cout, accumulate=accumulate)
     assert hip.conv_bnb_supported(cp)
-    mt = hip.conv_igemm_mtiles(cp)
+    cp.bnb = BnBwdFuse(ybn, mask_src, mean, invstd, scale, shift, relu, torch.zeros(cout * 2, device=DEV))
+    mt = hip.conv_igemm_mtiles(cp)          # rows of the descriptor AS LAUNCHED: the tile depends on the epilogue (include/sfk.h)
     parts_b = torch.full((mt * cout * 2,), float("nan"), device=DEV)
-    cp.bnb = BnBwdFuse(ybn, mask_src, mean, invstd, scale, shift, relu, parts_b)
+    cp.bnb.partials = parts_b
     hip.conv_igemm(cp)(stream())
     torch.cuda.synchronize()
     assert torch.equal(ya.buf.cpu().view(torch.int16), yb.buf.cpu().view(torch.int16))      # dz, and the untouched 8 pad channels

@@ -46,6 +46,7 @@ struct ConvK {
   FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   uint32_t ybytes, ep_rbytes; // ... and of y / the shortcut map (fused epilogue: branch-free loads)
+  uint32_t bn_ybytes, bn_mbytes, obits_bytes;   // ... and of the fused BatchNorm-backward epilogue's operands
   sfk_tap taps[SFK_MAX_TAPS];
 };
 
@@ -173,77 +174,110 @@ __device__ __forceinline__ float row16_sum(float v) {
 // statistics.  The stand-alone reduce kernel (read dA, read y, read the mask, write dz) disappears; the epilogue reads
 // y (and the mask source) for its own tile only.  Fragment pairs are processed one at a time so that only 8 channels'
 // coefficients are live.   `red` = WM x BN x 2 floats of LDS (aliases the ring; the caller has drained it).
+// All global loads are BRANCH-FREE buffer loads (rows past M re-read row M - 1, absent operands are zero-sized resources
+// that read zeros) and the loads of two pixel rows -- y_bn, the mask source or bitmap byte, the old value of a += pass --
+// are issued before the first use: with `if (m < M) { ... load ... }` hipcc drains vmcnt behind every load, up to twelve
+// serial round trips per lane and tile, which made this epilogue cost more than the reduce kernel it replaces.
 template <int FM, int FN, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&acc)[FN][FM], float* red, int mt, int nt,
                                                 int wm, int wn, int lane, int tid) {
   const int l15 = lane & 15, g = lane >> 4;
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
-  const bf16_t* __restrict__ by = static_cast<const bf16_t*>(k.bn_y);
-  const bf16_t* __restrict__ bm = static_cast<const bf16_t*>(k.bn_mask);
-  const bool bitmode = by == nullptr;     // mask = the output ReLU bitmap k.obits, only sum dz is left (fused block tail)
+  const bool bitmode = k.bn_y == nullptr;     // mask = the output ReLU bitmap k.obits, only sum dz is left (fused block tail)
+  const bool has_msrc = k.bn_mask != nullptr;
+  const bool relu_y = k.bn_relu && !has_msrc && !bitmode;       // mask from y * scale + shift > 0
   const int co_w = nt * BN + wn * (BN / WN);
+  const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
+  const __amdgpu_buffer_rsrc_t r_y = sfk_make_rsrc(k.bn_y, bitmode ? 0u : k.bn_ybytes);
+  const __amdgpu_buffer_rsrc_t r_m = sfk_make_rsrc(k.bn_mask, has_msrc ? k.bn_mbytes : 0u);
+  const __amdgpu_buffer_rsrc_t r_b = sfk_make_rsrc(k.obits, bitmode ? k.obits_bytes : 0u);
+  // the pixel a row maps to (clamped to the last row: nothing is stored for rows past M, their sums are masked out)
+  int64_t plin[FM];
+  bool rok[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m0 = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    rok[j] = m0 < k.M;
+    const int m = rok[j] ? m0 : k.M - 1;
+    if (k.lin_out) {
+      plin[j] = m;
+    } else {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      plin[j] = (((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo;
+    }
+  }
 #pragma unroll
   for (int p = 0; p < FN; p += 2) {
     const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);       // this lane's 8 channels after the swap
     const bool cok = co < k.cout;
+    const int cc = cok ? co : 0;
+    // per-channel coefficients: 16-byte buffer loads (zero-sized resource = zeros for an absent vector)
     float ca[8], cb[8], cs[8], ch[8];
+    {
+      const uint32_t cbo = (uint32_t)cc * 4u, nb = (uint32_t)k.cout * 4u;
+      const __amdgpu_buffer_rsrc_t r_is = sfk_make_rsrc(k.bn_invstd, bitmode ? 0u : nb);
+      const __amdgpu_buffer_rsrc_t r_mu = sfk_make_rsrc(k.bn_mean, bitmode ? 0u : nb);
+      const __amdgpu_buffer_rsrc_t r_sc = sfk_make_rsrc(k.bn_scale, relu_y ? nb : 0u);
+      const __amdgpu_buffer_rsrc_t r_sh = sfk_make_rsrc(k.bn_shift, relu_y ? nb : 0u);
+      const uint4 i0 = sfk_buffer_load16(r_is, cbo), i1 = sfk_buffer_load16(r_is, cbo + 16);
+      const uint4 m0 = sfk_buffer_load16(r_mu, cbo), m1 = sfk_buffer_load16(r_mu, cbo + 16);
+      const uint4 s0 = sfk_buffer_load16(r_sc, cbo), s1_ = sfk_buffer_load16(r_sc, cbo + 16);
+      const uint4 h0 = sfk_buffer_load16(r_sh, cbo), h1 = sfk_buffer_load16(r_sh, cbo + 16);
+      const uint32_t iv[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+      const uint32_t mv_[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      const uint32_t sv[8] = {s0.x, s0.y, s0.z, s0.w, s1_.x, s1_.y, s1_.z, s1_.w};
+      const uint32_t hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = cok ? co + e : 0;
-      const float is = bitmode ? 0.f : k.bn_invstd[c];
-      ca[e] = is;
-      cb[e] = bitmode ? 0.f : -k.bn_mean[c] * is;                   // x_hat = y * ca + cb
-      cs[e] = (k.bn_relu && !bm && !bitmode) ? k.bn_scale[c] : 0.f;
-      ch[e] = (k.bn_relu && !bm && !bitmode) ? k.bn_shift[c] : 1.f; // no mask: y*0 + 1 > 0
+      for (int e = 0; e < 8; ++e) {
+        const float is = __uint_as_float(iv[e]);                     // (bitmode: 0)
+        ca[e] = is;
+        cb[e] = -__uint_as_float(mv_[e]) * is;                        // x_hat = y * ca + cb
+        cs[e] = relu_y ? __uint_as_float(sv[e]) : 0.f;
+        ch[e] = relu_y ? __uint_as_float(hv[e]) : 1.f;                // no mask from y: y * 0 + 1 > 0
+      }
     }
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    constexpr int JB = FM >= 2 ? 2 : 1;       // pixel rows whose loads are in flight together (register budget of the 128-VGPR tiles)
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-      if (m < k.M) {
-        int64_t plin;
-        if (k.lin_out) {
-          plin = m;
-        } else {
-          uint32_t q1, rw_, q2, rh_, n_, rt_;
-          k.drw.divmod((uint32_t)m, q1, rw_);
-          k.drh.divmod(q1, q2, rh_);
-          k.drt.divmod(q2, n_, rt_);
-          const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
-          plin = (((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo;
-        }
+    for (int j0 = 0; j0 < FM; j0 += JB) {
+      bf16x8 oldv[JB], yv[JB], mv[JB];
+      uint32_t mbyte[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+        oldv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_old, (uint32_t)((plin[j] * k.yld + k.yoff + cc) * 2)));
+        yv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_y, (uint32_t)((plin[j] * k.bn_yld + k.bn_yoff + cc) * 2)));
+        mv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_m, (uint32_t)((plin[j] * k.bn_mld + k.bn_moff + cc) * 2)));
+        mbyte[jj] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r_b, (int)(plin[j] * (k.cout >> 3) + (cc >> 3)), 0, 0);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
         float v[8] = {acc[p][j][0], acc[p][j][1], acc[p][j][2], acc[p][j][3],
                       acc[p + 1][j][0], acc[p + 1][j][1], acc[p + 1][j][2], acc[p + 1][j][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
-        if (cok) {
-          bf16_t* op = yp + plin * k.yld + k.yoff + co;
-          if (k.accumulate) {
-            const bf16x8 old = *reinterpret_cast<const bf16x8*>(op);
+        const bool live = rok[j] && cok;
+        bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-          }
-          bf16x8 yv = {};
-          if (!bitmode) yv = *reinterpret_cast<const bf16x8*>(by + plin * k.bn_yld + k.bn_yoff + co);
-          bf16x8 mv;
-          if (bm) mv = *reinterpret_cast<const bf16x8*>(bm + plin * k.bn_mld + k.bn_moff + co);
-          const uint32_t mbyte = bitmode ? k.obits[plin * (k.cout >> 3) + (co >> 3)] : 0u;
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float yf = (float)yv[e];
-            const bool keep = bitmode ? ((mbyte >> e) & 1u) : (bm ? ((float)mv[e] > 0.f) : (yf * cs[e] + ch[e] > 0.f));
-            // dz is what the BatchNorm backward sees: the value as it is STORED (bf16), masked
-            const bf16_t dzb = (bf16_t)(keep ? v[e] : 0.f);
-            const float dz = (float)dzb;
-            o[e] = dzb;
-            s1[e] += dz;
-            s2[e] += dz * (yf * ca[e] + cb[e]);
-          }
-          *reinterpret_cast<bf16x8*>(op) = o;
+        for (int e = 0; e < 8; ++e) {
+          const float vv = v[e] + (float)oldv[jj][e];                 // (no accumulate: zero-sized resource, + 0)
+          const float yf = (float)yv[jj][e];
+          const bool keep = bitmode ? ((mbyte[jj] >> e) & 1u) : (has_msrc ? ((float)mv[jj][e] > 0.f) : (yf * cs[e] + ch[e] > 0.f));
+          // dz is what the BatchNorm backward sees: the value as it is STORED (bf16), masked
+          const bf16_t dzb = (bf16_t)(keep ? vv : 0.f);
+          const float dz = live ? (float)dzb : 0.f;
+          o[e] = dzb;
+          s1[e] += dz;
+          s2[e] += dz * (yf * ca[e] + cb[e]);
         }
+        if (live) *reinterpret_cast<bf16x8*>(yp + plin[j] * k.yld + k.yoff + co) = o;
       }
     }
 #pragma unroll
@@ -1062,7 +1096,8 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
       const int64_t g256 = ((M + 255) / 256 + 255) / 256 * 256, g224 = ((M + 223) / 224 + 255) / 256 * 224;
       return {(sfk_tune().igemm_tile256 & 2) && g224 < g256 ? 224 : 256, 256, true};
     }
-    if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr) return {256, 128, true};
+    // (the fused BatchNorm-backward epilogue keeps two rows of y_bn / mask / old values in flight: the 4-wave tile's register budget)
+    if (M >= 256 * 128 && ktot > sfk_tune().igemm_small_k && !d->ep.res.ptr && !d->bnb.partials) return {256, 128, true};
     return {128, 128, true};
   }
   if (cout > 64) return {128, 128, false};
@@ -1074,7 +1109,7 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
 // the fused BatchNorm-backward epilogue exists for bf16 tiles with an even number of co fragments and 16-byte stores
 inline bool bnb_ok(const sfk_conv_desc* d) {
   return d->x.dtype == SFK_BF16 && d->cout > 16 && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0 &&
-         (((uintptr_t)d->y.ptr) & 15) == 0;
+         (((uintptr_t)d->y.ptr) & 15) == 0 && sfk_fmap_bytes(&d->y) < (1ll << 31);   // (y_bn / the mask share y's pixel grid)
 }
 
 // out_relu_bits: the pass must write every pixel of y in row order (the bitmap is indexed by the row), and bf16 needs
@@ -1158,6 +1193,11 @@ int validate(const sfk_conv_desc* d) {
     if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64 || (e.res.ptr && sfk_fmap_bytes(&e.res) >= (1ll << 32) - 64))
       return SFK_ERR_UNSUPPORTED;
   }
+  if (d->bnb.partials) {   // the fused epilogue reads y (+=), y_bn and the mask through 32-bit buffer resources
+    if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64) return SFK_ERR_UNSUPPORTED;
+    if (d->bnb.y_bn.ptr && sfk_fmap_ok(&d->bnb.y_bn) && sfk_fmap_bytes(&d->bnb.y_bn) >= (1ll << 32) - 64) return SFK_ERR_UNSUPPORTED;
+    if (d->bnb.mask_src.ptr && sfk_fmap_ok(&d->bnb.mask_src) && sfk_fmap_bytes(&d->bnb.mask_src) >= (1ll << 32) - 64) return SFK_ERR_UNSUPPORTED;
+  }
   if (bnb_bits) {
     if (!d->out_relu_bits || d->stats || d->bnb.mask_src.ptr) return SFK_ERR_INVALID;
     if (!bnb_ok(d) || !lin_out_of(d)) return SFK_ERR_UNSUPPORTED;
@@ -1190,8 +1230,7 @@ int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
     return SFK_OK;
   }
   if (k.bn_parts) {
-    if (bm == 256) hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2, 1>), grid, dim3(512), 0, s, k);
-    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);   // (pick_tile: never 256 x 128)
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
@@ -1246,6 +1285,9 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.ep_relu = d->ep.relu; k.ep_bits = d->ep.relu_bits;
   k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
   k.ep_rbytes = d->ep.res.ptr ? (uint32_t)sfk_fmap_bytes(&d->ep.res) : 0u;
+  k.bn_ybytes = (k.bn_parts && d->bnb.y_bn.ptr) ? (uint32_t)sfk_fmap_bytes(&d->bnb.y_bn) : 0u;
+  k.bn_mbytes = (k.bn_parts && d->bnb.mask_src.ptr) ? (uint32_t)sfk_fmap_bytes(&d->bnb.mask_src) : 0u;
+  k.obits_bytes = d->out_relu_bits ? (uint32_t)(sfk_fmap_pixels(&d->y) * (d->cout / sfk_vec_of(d->x.dtype))) : 0u;
   k.kshort = sfk_tune().igemm_short_k;
   k.lin_out = lin_out_of(d);
   const int wide_ok = sfk_tune().igemm_wide_store;

@@ -63,6 +63,21 @@ class _UnitRec:
     shift: torch.Tensor
 
 
+def _cu_masked_stream(device, ncu: int):
+    """a HIP stream whose kernels only run on `ncu` compute units (hipExtStreamCreateWithCUMask), wrapped for torch"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = 8                                   # 256 CUs
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(min(ncu, 32 * words)):
+        mask[i // 32] |= 1 << (i % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    assert rc == 0, f"hipExtStreamCreateWithCUMask: {rc}"
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class Wait:
     """Schedule marker: stream of pathway `lane` must wait for everything issued so far on pathway `on`.
     A no-op when the schedule runs on a single stream (stream order already implies it)."""
@@ -502,9 +517,12 @@ class Engine:
             extra = 0.0
             if fuse is not None and self.fuse_bn_bwd and len(passes) == 1 and self.be.conv_bnb_supported(cp):
                 brec, mask_src, relu, tag = fuse
+                # the tile -- hence the number of partial rows -- depends on the epilogue: ask with the descriptor AS LAUNCHED
+                cp.bnb = BnBwdFuse(brec.y, mask_src, brec.mean, brec.invstd, brec.scale, brec.shift, relu,
+                                   self._buf(f"bparts.{tag}", brec.L.c * 2, torch.float32))
                 mt = self.be.conv_igemm_mtiles(cp)
                 parts = self._buf(f"bparts.{tag}", max(mt, 1) * brec.L.c * 2, torch.float32)
-                cp.bnb = BnBwdFuse(brec.y, mask_src, brec.mean, brec.invstd, brec.scale, brec.shift, relu, parts)
+                cp.bnb.partials = parts
                 reduced = (parts, mt)
                 extra = float(esz * rows * L.eg.cin * (2 if mask_src is not None else 1))
             elif out_sum_tag is not None:
@@ -513,14 +531,15 @@ class Engine:
                 # stays unmasked and that block's own mask pass (sfk_bn_bwd_reduce, y = NULL) does it
                 if out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp) \
                         and self.be.conv_bnb_supported(cp):
+                    cp.relu_out_bits = out_bits
+                    cp.bnb = BnBwdFuse(None, None, None, None, None, None, True,
+                                       self._buf(f"bparts.{out_sum_tag}.c", self.max_parts * L.eg.cin * 2, torch.float32))
+                    # the row count is a property of the descriptor AS LAUNCHED (the tile depends on the epilogue; the streaming
+                    # pointwise kernel leaves one row per wave, at most max_parts): ask now that the epilogue is set
                     mt = self.be.conv_igemm_mtiles(cp)
                     parts = self._buf(f"bparts.{out_sum_tag}.c", max(mt, self.max_parts) * L.eg.cin * 2, torch.float32)
-                    cp.relu_out_bits = out_bits
-                    cp.bnb = BnBwdFuse(None, None, None, None, None, None, True, parts)
-                    # the row count is a property of the descriptor AS LAUNCHED (the streaming pointwise kernel leaves one
-                    # row per wave, at most max_parts): ask again now that the epilogue is set
-                    mt = self.be.conv_igemm_mtiles(cp)
-                    assert mt <= max(mt, self.max_parts) and parts.numel() >= mt * L.eg.cin * 2
+                    cp.bnb.partials = parts
+                    assert parts.numel() >= mt * L.eg.cin * 2
                     reduced = ("masked+sum", parts, mt)
                     extra = float(rows * L.eg.cin // self.kvec)
             elif out_bits is not None and len(passes) == 1 and self.be.conv_relu_out_supported(cp):
@@ -1097,6 +1116,10 @@ class Engine:
             return [main]
         if self._side is None:
             self._side = [torch.cuda.Stream(self.device) for _ in range(self.NLANES - 1)]
+            ncu = int(os.environ.get("SFK_WG_CUS", "0"))
+            if ncu > 0:      # EXPERIMENT: the filter-gradient lanes on streams restricted to the first `ncu` CUs of the mask
+                for lane in (2, 3):
+                    self._side[lane - 1] = _cu_masked_stream(self.device, ncu)
         return [main] + self._side
 
     def _run_lanes(self, ops: "OpList", begin: int = 0, end: Optional[int] = None):
@@ -1111,7 +1134,8 @@ class Engine:
         skip = self._ablate_kinds
         for i in range(begin, end):
             op, lane = ops[i], ops.lane[i]
-            if skip and ops.meta[i] is not None and ops.meta[i].get("kind") in skip:
+            if skip and not isinstance(op, Wait) and ((ops.meta[i] is not None and ops.meta[i].get("kind") in skip)
+                                                      or f"lane{lane}" in skip):
                 continue                 # TIMING ABLATION ONLY (SFK_ABLATE): the step's results are wrong
             if isinstance(op, Wait):
                 ev = torch.cuda.Event()
