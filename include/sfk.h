@@ -37,8 +37,9 @@ extern "C" {
 /* Bumped on EVERY change of a struct layout, a prototype or the meaning of an argument / tuning field.  include/sfk.abi holds
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
- * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256. */
-#define SFK_ABI_VERSION 11
+ * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256; 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
+ * of `a` from it (no constant-1 channel group beside the activation any more). */
+#define SFK_ABI_VERSION 12
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -256,10 +257,13 @@ int sfk_bn_stats(const sfk_fmap* y, float* partials, int32_t max_parts, int32_t*
  * (stem / bottleneck norm+act, ResBlock "x + branch2(x)" then ReLU.)
  * relu_bits (optional, needs relu): the ReLU mask as one bit per element, byte [pixel][c / V] holding the V sign bits of
  * channel group g (V = 8 for bf16, 4 for f32; bit i = (a[pixel][g*V + i] > 0)) -- 1/16 of a bf16 map.  The backward of
- * a block output reads these instead of the activation (sfk_bn_bwd_reduce). */
+ * a block output reads these instead of the activation (sfk_bn_bwd_reduce).
+ * out_sums (optional; plain ReLU apply without shortcut only): partial column sums of the output AS STORED,
+ * out_sums[nparts][c][2] = (sum a, 0), nparts <= max_parts returned through *nparts_out (host) -- the g = 1^T a of the fused
+ * block tail (sfk_bn_tail_fwd) for free while `a` is written. */
 int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
                  const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
-                 uint8_t* relu_bits, sfk_stream_t stream);
+                 uint8_t* relu_bits, float* out_sums, int32_t max_parts, int32_t* nparts_out, sfk_stream_t stream);
 
 /* Backward of a = act(bn(y) [+ shortcut]) given dA:
  *   dz = dA * mask,   mask = relu_bits (as written by sfk_bn_apply) if given, else (mask_src > 0) if mask_src,
@@ -290,13 +294,17 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
  *     sum dz*y[co] = W[co] . R[co];  dy = A dz + B y + C per channel (A = gamma*invstd, B = -A*c2*invstd,
  *     C = A*(c2*invstd*mean - c1), c1 = s/n, c2 = invstd*(sum dz*y - mean*s)/n), hence
  *     dW = diag(A) R + diag(B) (W G) + C (x) g,     da = dz (diag(A) W) + a (W^T diag(B) W) + (C W).
- * The caller keeps `a` with ONE extra channel group whose first channel is the constant 1 (pixel stride ld = c + V,
- * V = 16 / sizeof(dtype)), so the ordinary filter-gradient kernel delivers everything in two calls:
- *     gram = sfk_conv_wgrad(x = a[0 : c+V), dy = a[0 : c+V))  -> [c+V][c+V]: G, row c = g, element (c, c) = n
- *     r    = sfk_conv_wgrad(x = a[0 : c), dy = dz)            -> [cout][c]: R;  s = sum dz comes as partial rows from the
- *            kernel that wrote dz (its ReLU-mask pass)
- * sfk_bn_tail_fwd: batch statistics / running-stat update / scale, shift as sfk_bn_finalize, from `gram` (the variance is
- *   W Gc W^T over the CENTRED matrix Gc = G/n - (g/n)(g/n)^T formed in double: no E[y^2] - E[y]^2 cancellation); also
+ * G is one ordinary filter-gradient call, g comes from the pass that wrote `a`, R is another filter-gradient call:
+ *     gram = sfk_conv_wgrad(x = a, dy = a)       -> [c][c]: G   (one staged tile serves both operands)
+ *     a_sums = sfk_bn_apply(..., out_sums)       -> partial column sums of a; n = the pixel count
+ *     r    = sfk_conv_wgrad(x = a, dy = dz)      -> [cout][c]: R;  s = sum dz comes as partial rows from the kernel that wrote
+ *            dz (its ReLU-mask pass)
+ * (Rounds 1-2 kept `a` widened by a constant-1 channel group so that one filter-gradient call delivered G, g and n; on the
+ * fast pathway's 8 .. 32-channel maps that doubled .. 1.25x-ed every pass over `a`, and 128 + 8 columns fell off the 128-wide
+ * tile.)
+ * sfk_bn_tail_fwd: folds a_sums into g [c] (caller's scratch, kept for the backward); batch statistics / running-stat update /
+ *   scale, shift as sfk_bn_finalize, from G, g and count = n (the variance is W Gc W^T over the CENTRED matrix
+ *   Gc = G/n - (g/n)(g/n)^T formed in double: no E[y^2] - E[y]^2 cancellation); also
  *   leaves t = W G ([cout][c] fp32) for the backward and, when wd != NULL, the filter of the backward's first
  *   data-gradient pass  wd [c][cout] (w_dtype) = (A W)^T, A = gamma * invstd  -> pass 1: da = dz . wd (sfk_conv_igemm, plain).
  *   A needs the forward statistics only, so pass 1 does not wait for R: it runs beside the R filter-gradient call.
@@ -305,12 +313,13 @@ int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask
  *     m [c][c] (w_dtype) = W^T diag(B) W   -> pass 2: da += a . m + bias   (sfk_conv_igemm, accumulate + ep.shift)
  *     bias [c] fp32 = C W
  */
-int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
+int sfk_bn_tail_fwd(const float* gram, const float* a_sums, int32_t a_nparts, int64_t count, float* g, int32_t c,
+                    const void* w, int32_t w_dtype, int32_t cout,
                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
                     float* shift, float* t, void* wd, sfk_stream_t stream);
-int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, const float* gram, const float* t,
-                    int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma,
+int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, const float* g, int64_t count, const float* t,
+                    int32_t c, const void* w, int32_t w_dtype, int32_t cout, const float* gamma,
                     const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dw, void* m,
                     float* bias, float* coef, sfk_stream_t stream);
 /* r [cout][c]; dz_partials [nparts][cout][2], component 0 = partial sums of dz as the kernel that WROTE dz left them

@@ -141,14 +141,17 @@ class EmuBackend:
         return tuple(p.os) == (1, 1, 1) and tuple(p.oo) == (0, 0, 0) and tuple(p.rows) == (p.y.t, p.y.h, p.y.w)
 
     # ------------------------------------------------------------------ bottleneck tail (sfk_bn_tail_*, sfk_relu_bits_mask)
-    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, t, wd=None):
+    def bn_tail_fwd(self, gram, a_sums, a_nparts, count, g, c, w, cout, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd,
+                    scale, shift, t, wd=None):
         def run(stream):
-            Gx = gram[: gld * gld].view(gld, gld).double()
-            G, g, n = Gx[:c, :c], Gx[c, :c], float(Gx[c, c])
+            G = gram[: c * c].view(c, c).double()
+            gs = a_sums[: a_nparts * c * 2].view(a_nparts, c, 2)[:, :, 0].double().sum(0)
+            g[:c].copy_(gs.float())
+            g_, n = gs, float(count)
             W = w[: cout * c].view(cout, c).double()
             T = W @ G
             t[: cout * c].copy_(T.float().reshape(-1))
-            mu = (W @ g) / n
+            mu = (W @ g_) / n
             var = ((T * W).sum(1) / n - mu * mu).clamp_min(0.0)
             is_ = 1.0 / torch.sqrt(var + eps)
             mean[:cout].copy_(mu.float())
@@ -166,13 +169,12 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
+    def bn_tail_bwd(self, r, dz_partials, nparts, g_in, count, t, c, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
                     bias, coef):
         def run(stream):
             R = r[: cout * c].view(cout, c).double()
             s_ = dz_partials[: nparts * cout * 2].view(nparts, cout, 2)[:, :, 0].double().sum(0)
-            Gx = gram[: gld * gld].view(gld, gld).double()
-            g, n = Gx[c, :c], float(Gx[c, c])
+            g, n = g_in[:c].double(), float(count)
             W = w[: cout * c].view(cout, c).double()
             T = t[: cout * c].view(cout, c).double()
             is_, mu = invstd[:cout].double(), mean[:cout].double()
@@ -288,7 +290,7 @@ class EmuBackend:
     def _vec(y):
         return 8 if y.dtype == torch.bfloat16 else 4
 
-    def bn_apply(self, y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=None):
+    def bn_apply(self, y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=None, out_sums=None, max_parts=0):
         def run(stream):
             c = y.c
             v = y.view5().float() * scale[:c] + shift[:c]
@@ -305,6 +307,12 @@ class EmuBackend:
                     relu_bits[: pos.shape[0] * (c // vec)] = (pos * wts).sum(-1).to(torch.uint8).reshape(-1)
                 v = v.clamp_min(0)
             out.view5().copy_(v.to(out.dtype))
+            if out_sums is not None:                            # column sums of the output AS STORED: ONE partial row
+                out_sums[: 2 * c].view(c, 2).zero_()
+                out_sums[: 2 * c].view(c, 2)[:, 0] = out.view5().float().reshape(-1, c).sum(0)
+        if out_sums is not None:
+            assert res is None and relu and max_parts > 0
+            return run, 1
         return run
 
     @staticmethod

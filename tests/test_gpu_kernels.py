@@ -773,24 +773,25 @@ def test_bottleneck_tail_variance_of_mean_dominated_channels(hip):
     """sfk_bn_tail_fwd on channels whose mean dwarfs their spread (mean^2 / var = 1e3 .. 1e4, e.g. a ReLU output far from zero
     under a same-sign filter row): the variance comes from the centred Gram matrix, so it keeps its digits where
     E[y^2] - E[y]^2 on an fp32 T = W G loses mean^2 / var of them.  Checked against the float64 variance of y = a W^T with the
-    Gram matrix as exact as fp32 holds it (rounded once from float64)."""
+    Gram matrix and the column sums as exact as fp32 holds them (rounded once from float64)."""
     gen = torch.Generator().manual_seed(5)
-    px, c, cout, V = 4096, 64, 32, 4
-    gld = c + V
+    px, c, cout = 4096, 64, 32
     for ratio in (1e3, 1e4):
         a = torch.randn(px, c, generator=gen, dtype=torch.float64) + ratio ** 0.5 * 3.0      # every column: mean^2 / var ~ 9 ratio
         W = torch.rand(cout, c, generator=gen, dtype=torch.float64) * 0.2 + 0.05                 # same-sign rows: the means add up
-        aw = torch.cat([a, torch.ones(px, 1, dtype=torch.float64), torch.zeros(px, V - 1, dtype=torch.float64)], 1)
-        gram = (aw.t() @ aw).float().to(DEV).reshape(-1)
+        gram = (a.t() @ a).float().to(DEV).reshape(-1)
+        asums = torch.zeros(c * 2, device=DEV)
+        asums.view(c, 2)[:, 0] = a.sum(0).float().to(DEV)                                       # ONE partial row
         y = a @ W.t()
         want_mu, want_var = y.mean(0), y.var(0, unbiased=False)
         assert float((want_mu ** 2 / want_var).min()) > ratio
         f = lambda k: torch.zeros(k, device=DEV)
-        mean, invstd, scale, shift, t = f(cout), f(cout), f(cout), f(cout), f(cout * c)
+        mean, invstd, scale, shift, t, gvec = f(cout), f(cout), f(cout), f(cout), f(cout * c), f(c)
         rm, rv, nbt = f(cout), torch.ones(cout, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
-        hip.bn_tail_fwd(gram, c, gld, W.float().to(DEV).reshape(-1), cout, torch.ones(cout, device=DEV), f(cout), 1e-5, 0.1,
-                        rm, rv, nbt, mean, invstd, scale, shift, t)(stream())
+        hip.bn_tail_fwd(gram, asums, 1, px, gvec, c, W.float().to(DEV).reshape(-1), cout, torch.ones(cout, device=DEV), f(cout),
+                        1e-5, 0.1, rm, rv, nbt, mean, invstd, scale, shift, t)(stream())
         torch.cuda.synchronize()
+        assert rel_err(gvec.cpu(), a.sum(0).float()) < 1e-6
         got_var = 1.0 / invstd.cpu().double() ** 2 - 1e-5
         # what limits it now is G itself: one fp32 rounding of entries ~ n mean^2 is 6e-8 mean^2 / var relative to the variance
         bound = 4 * 6e-8 * float((want_mu ** 2 / want_var).max()) + 1e-5

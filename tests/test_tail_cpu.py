@@ -37,26 +37,26 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     n, t, h, w, c = a.shape
     cout = W.shape[0]
     vec = 8 if dtype == torch.bfloat16 else 4
-    gld = c + vec
     f32 = lambda *s: torch.zeros(*s, device=dev)
-    # `a` lives widened by one channel group whose first channel is the constant 1
-    ab = torch.zeros(n * t * h * w * gld, dtype=dtype, device=dev)
-    full = FMap(ab, n, t, h, w, gld, gld, 0)
-    full.view5()[..., :c].copy_(a.to(dtype))
-    full.view5()[..., c] = 1.0
-    av = full.channels(0, c)
+    av = FMap(a.to(dtype).to(dev).reshape(-1).contiguous(), n, t, h, w, c)
     wq = W.to(dtype).to(dev).reshape(-1).contiguous()                  # compute-precision filter [cout][c]
     g_, b_ = gamma.float().to(dev), beta.float().to(dev)
     rmap = FMap(res.to(dtype).to(dev).reshape(-1).contiguous(), n, t, h, w, cout)
     out = FMap(torch.zeros(n * t * h * w * cout, dtype=dtype, device=dev), n, t, h, w, cout)
     bits = torch.zeros(out.pixels * (cout // vec), dtype=torch.uint8, device=dev)
-    # ---- forward
-    gram = f32(gld * gld)
-    be.conv_wgrad(WgradPass(full, full, ONE, TAP0, gram, 1, gld, gld))(stream)
+    # ---- forward: G = a^T a (one filter-gradient call), the column sums of a as partial rows (the engine gets them from the
+    # sfk_bn_apply pass that writes a; here a is given, so a statistics pass leaves the same rows: component 0 = sum)
+    gram = f32(c * c)
+    be.conv_wgrad(WgradPass(av, av, ONE, TAP0, gram, 1, c, c))(stream)
+    asums = f32(1024 * c * 2)
+    run, a_np = be.bn_stats(av, asums, 1024)
+    run(stream)
+    gvec = f32(c)
     mean, invstd, scale, shift, T = f32(cout), f32(cout), f32(cout), f32(cout), f32(cout * c)
     rm, rv, nbt = f32(cout), torch.ones(cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
     wd = torch.zeros(cout * c, dtype=dtype, device=dev)                # (A W)^T: known once the statistics are
-    be.bn_tail_fwd(gram, c, gld, wq, cout, g_, b_, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, T, wd)(stream)
+    be.bn_tail_fwd(gram, asums, a_np, av.pixels, gvec, c, wq, cout, g_, b_, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift,
+                   T, wd)(stream)
     ep = ConvEpilogue(scale=scale, shift=shift, res=rmap, relu=True, relu_bits=bits)
     if res_affine is not None:
         ep.res_scale, ep.res_shift = res_affine
@@ -72,7 +72,7 @@ def run_tail(be, dev, dtype, a, W, gamma, beta, res, gout, stream=0, eps=1e-5, m
     be.conv_wgrad(WgradPass(av, dz, ONE, TAP0, r, 1, c, cout))(stream)
     dgamma, dbeta, dw, bias, coef = f32(cout), f32(cout), f32(cout * c), f32(c), f32(cout * 4)
     m = torch.zeros(c * c, dtype=dtype, device=dev)
-    be.bn_tail_bwd(r, parts, nparts, gram, T, c, gld, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, m, bias, coef)(stream)
+    be.bn_tail_bwd(r, parts, nparts, gvec, av.pixels, T, c, wq, cout, g_, mean, invstd, dgamma, dbeta, dw, m, bias, coef)(stream)
     da = FMap(torch.zeros(n * t * h * w * c, dtype=dtype, device=dev), n, t, h, w, c)
     be.conv_igemm(ConvPass(dz, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, wd, 1, cout, c))(stream)
     be.conv_igemm(ConvPass(av, da, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, m, 1, c, c, accumulate=True,

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 11       # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 12       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -219,8 +219,8 @@ SIGNATURES = {
     "sfk_conv_relu_out_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_epilogue_supported": [C.POINTER(_ConvDesc)],
     "sfk_conv_igemm_family": [C.POINTER(_ConvDesc)],
-    "sfk_bn_tail_fwd": [_PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV, _PV],
-    "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _PF, _I32, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PF, _PF, _PV],
+    "sfk_bn_tail_fwd": [_PF, _PF, _I32, _I64, _PF, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV, _PV],
+    "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _I64, _PF, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PF, _PF, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_conv_wgrad_dg_supported": [C.POINTER(_WgradDesc)],
@@ -232,7 +232,7 @@ SIGNATURES = {
     "sfk_bn_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV],
     "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
     "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
-    "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV, _PV],
+    "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV, _PF, _I32, C.POINTER(C.c_int32), _PV],
     "sfk_bn_bwd_reduce": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _P_FMAP, _PF, _I32,
                           C.POINTER(C.c_int32), _PV, _PV],
     "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PF, _PV],
@@ -541,16 +541,25 @@ class HipBackend:
         return max(1, parts)
 
     def bn_apply(self, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap,
-                 relu_bits=None):
-        """relu_bits: optional uint8 tensor of pixels * c / V bytes (V = 8 bf16, 4 f32) that receives the ReLU mask."""
+                 relu_bits=None, out_sums=None, max_parts: int = 0):
+        """relu_bits: optional uint8 tensor of pixels * c / V bytes (V = 8 bf16, 4 f32) that receives the ReLU mask.
+        out_sums: optional fp32 [max_parts][c][2] that receives the partial column sums of the output; then the call returns
+        (run, nparts) -- nparts is fixed by the geometry, the library reports it when the launch is configured"""
         fy, fo = _c_fmap(y), _c_fmap(out)
         fr = _c_fmap(res) if res is not None else None
         if relu_bits is not None:
             vec = 8 if y.dtype == torch.bfloat16 else 4
             assert relu_bits.dtype == torch.uint8 and relu_bits.numel() >= y.pixels * (y.c // vec)
-        return self._plain("sfk_bn_apply", C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fr) if fr else None,
-                           _ptr(res_scale), _ptr(res_shift), 1 if relu else 0, C.byref(fo), _ptr(relu_bits),
-                           keep=(fy, fo, fr, y, out, res, scale, shift, res_scale, res_shift, relu_bits))
+        np_ = C.c_int32(0)
+        if out_sums is not None:
+            assert max_parts > 0 and out_sums.numel() >= max_parts * y.c * 2
+        run = self._plain("sfk_bn_apply", C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fr) if fr else None,
+                          _ptr(res_scale), _ptr(res_shift), 1 if relu else 0, C.byref(fo), _ptr(relu_bits), _ptr(out_sums),
+                          max_parts, C.byref(np_) if out_sums is not None else None,
+                          keep=(fy, fo, fr, np_, y, out, res, scale, shift, res_scale, res_shift, relu_bits, out_sums))
+        if out_sums is None:
+            return run
+        return run, self._dry_parts(y, max_parts)
 
     def bn_bwd_reduce(self, da: FMap, y: FMap, mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool,
                       dz_out: Optional[FMap], partials, max_parts, relu_bits=None):
@@ -583,19 +592,21 @@ class HipBackend:
                            keep=(fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift, coef))
 
     # -- the bottleneck tail (conv_c -> norm_c without the conv output in HBM)
-    def bn_tail_fwd(self, gram, c, gld, w, cout, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
-                    scale, shift, t, wd=None):
-        """wd: optional [c][cout] filter (A W)^T of the backward's first data-gradient pass (include/sfk.h)"""
-        ts = (gram, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t, wd)
-        return self._plain("sfk_bn_tail_fwd", _ptr(gram), c, gld, _ptr(w), _DT[w.dtype], cout, _ptr(gamma), _ptr(beta), eps,
-                           momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd),
-                           _ptr(scale), _ptr(shift), _ptr(t), _ptr(wd), keep=ts)
+    def bn_tail_fwd(self, gram, a_sums, a_nparts, count, g, c, w, cout, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                    mean, invstd, scale, shift, t, wd=None):
+        """gram [c][c]; a_sums: the partial column sums bn_apply left for `a` (a_nparts rows), folded into g [c] (kept for the
+        backward); count = pixels.  wd: optional [c][cout] filter (A W)^T of the backward's first data-gradient pass"""
+        ts = (gram, a_sums, g, w, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, t, wd)
+        return self._plain("sfk_bn_tail_fwd", _ptr(gram), _ptr(a_sums), a_nparts, count, _ptr(g), c, _ptr(w), _DT[w.dtype], cout,
+                           _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean),
+                           _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(t), _ptr(wd), keep=ts)
 
-    def bn_tail_bwd(self, r, dz_partials, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
+    def bn_tail_bwd(self, r, dz_partials, nparts, g, count, t, c, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m,
                     bias, coef):
-        """m: [c][c] filter (compute precision) of the second data-gradient pass, W^T diag(B) W (include/sfk.h)"""
-        ts = (r, dz_partials, gram, t, w, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef)
-        return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(gram), _ptr(t), c, gld, _ptr(w),
+        """g [c], count: what bn_tail_fwd folded / was given.  m: [c][c] filter (compute precision) of the second
+        data-gradient pass, W^T diag(B) W (include/sfk.h)"""
+        ts = (r, dz_partials, g, t, w, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef)
+        return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(g), count, _ptr(t), c, _ptr(w),
                            _DT[w.dtype], cout, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
                            _ptr(m), _ptr(bias), _ptr(coef), keep=ts)
 

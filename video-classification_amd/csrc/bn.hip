@@ -69,7 +69,10 @@ __device__ __forceinline__ void load_coef(float (&dst)[VEC], const float* src, i
   for (int i = 0; i < VEC; ++i) dst[i] = src[cg * VEC + i];
 }
 
-// block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group
+// block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group: rows_b = 256 / cgs_b row
+// lanes per group.  Two levels in a fixed order (deterministic): R2 row lanes each add rows r, r + R2, ... in order, then row
+// lane 0 adds the R2 partial sums.  (One level -- row lane 0 walking all rows_b rows -- was a serial tail of up to 256 x 16
+// LDS reads on the 8 .. 32-channel maps of the fast pathway: 5 .. 8 us of a 17 us kernel.)
 template <int VEC>
 __device__ __forceinline__ void block_reduce_store(const ChanMap& cm, int cgs, const float (&a)[VEC],
                                                    const float (&b)[VEC], float* partials, int c) {
@@ -82,16 +85,37 @@ __device__ __forceinline__ void block_reduce_store(const ChanMap& cm, int cgs, c
   }
   __syncthreads();
   const int cgs_b = cgs < 256 ? cgs : 256;
-  const int ty = threadIdx.x / cgs_b;
-  if (ty == 0 && cm.cg < cgs) {
-    float sa[VEC], sb[VEC];
+  const int ty = threadIdx.x / cgs_b, tx = threadIdx.x % cgs_b;
+  const int R2 = cm.rows_b >= 64 ? 16 : (cm.rows_b >= 16 ? 4 : 1);     // second-level fan-in
+  float sa[VEC], sb[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-    for (int r = 0; r < cm.rows_b; ++r) {
-      const float* o = red + (r * cgs_b + threadIdx.x) * 2 * VEC;
+  for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+  const bool lvl1 = ty < R2 && ty < cm.rows_b && cm.cg < cgs;
+  if (lvl1) {
+    for (int r = ty; r < cm.rows_b; r += R2) {
+      const float* o = red + (r * cgs_b + tx) * 2 * VEC;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { sa[i] += o[2 * i]; sb[i] += o[2 * i + 1]; }
     }
+  }
+  if (R2 > 1) {
+    __syncthreads();                     // every level-1 read of `red` is done before it is overwritten
+    if (lvl1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { mine[2 * i] = sa[i]; mine[2 * i + 1] = sb[i]; }
+    }
+    __syncthreads();
+    if (ty == 0 && cm.cg < cgs) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+      for (int r = 0; r < R2 && r < cm.rows_b; ++r) {
+        const float* o = red + (r * cgs_b + tx) * 2 * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { sa[i] += o[2 * i]; sb[i] += o[2 * i + 1]; }
+      }
+    }
+  }
+  if (ty == 0 && cm.cg < cgs) {
     float* out = partials + ((int64_t)blockIdx.x * c + cm.cg * VEC) * 2;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { out[2 * i] = sa[i]; out[2 * i + 1] = sb[i]; }
@@ -235,15 +259,22 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // RES: 0 none, 1 plain residual, 2 residual with its own scale/shift (projection shortcut's BN)
 // relu_bits (optional, RELU only): one bit per output element, byte [pixel][channel group] = the VEC sign bits of the
 // group -- 1/16 of the bf16 map.  The backward of act(bn(y) + shortcut) reads it instead of the activation itself.
-template <typename T, int RES, bool RELU, int NT>
+// SUMS: the block also leaves the column sums of what it STORED as one partial row [c][2] = (sum a, 0) -- the fused block
+// tail takes g = 1^T a from these (sfk_bn_tail_fwd) instead of a constant-1 channel group beside every pixel.
+template <typename T, int RES, bool RELU, int NT, bool SUMS = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
                                                        const float* scale, const float* shift,
-                                                       const float* rscale, const float* rshift, uint8_t* relu_bits) {
+                                                       const float* rscale, const float* rshift, uint8_t* relu_bits,
+                                                       float* sums = nullptr) {
   constexpr int nt = NT;   // compile time: a run-time choice between the two access flavours is merged into plain accesses
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
-  if (!cm.active) return;
+  float asum[VEC], zsum[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { asum[i] = 0.f; zsum[i] = 0.f; }
+  if (!SUMS && !cm.active) return;
+  if (cm.active) {
   float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
   load_coef<VEC>(sc, scale, cm.cg);
   load_coef<VEC>(sh, shift, cm.cg);
@@ -286,12 +317,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
           f = f > 0.f ? f : 0.f;
         }
         o.set(i, f);
+        if (SUMS) asum[i] += o.get(i);
       }
       if (nt & 1) o.store_nt(op + p * out.ld);
       else o.store(op + p * out.ld);
       if (RELU && relu_bits) relu_bits[p * cgs + cm.cg] = (uint8_t)bits;
     }
   }
+  }
+  if (SUMS) block_reduce_store<VEC>(cm, cgs, asum, zsum, sums, c);
 }
 
 // ------------------------------------------------------------------ backward
@@ -623,15 +657,24 @@ extern "C" int sfk_bn_eval_coeffs(const float* gamma, const float* beta, const f
 namespace {
 template <typename T>
 int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
-                 const float* rs, const float* rb, int relu, const sfk_fmap* out, uint8_t* bits, hipStream_t s) {
+                 const float* rs, const float* rb, int relu, const sfk_fmap* out, uint8_t* bits, float* sums, int max_parts,
+                 int* nparts_out, hipStream_t s) {
   const int64_t px = sfk_fmap_pixels(y);
   int np;
-  dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np);
+  dim3 grid = chan_grid(y->c / DT<T>::VEC, px, sums ? max_parts : 0, &np);
   const dim3 blk(256);
-  grid.x = span_blocks(y->c / DT<T>::VEC, px);      // one span per thread: no grid-stride loop
   const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
   const int mode = !res ? 0 : (rs ? 2 : 1);
   const int nt = nt_hint(y, sfk_tune().nt_apply_mb, 3);
+  if (sums) {       // one partial row per block: the capped grid of the reductions (grid-stride loop over the spans)
+    if (mode != 0 || !relu) return SFK_ERR_UNSUPPORTED;
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<T, 0, true, 3, true>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits, sums);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 0, true, 0, true>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits, sums);
+    SFK_CHECK_LAUNCH();
+    *nparts_out = np;
+    return SFK_OK;
+  }
+  grid.x = span_blocks(y->c / DT<T>::VEC, px);      // one span per thread: no grid-stride loop
 #define SFK_APPLY(R, A)                                                                                                      \
   do {                                                                                                                     \
     if (nt) hipLaunchKernelGGL((bn_apply_kernel<T, R, A, 3>), grid, blk, 0, s, fy, fr, fo, px, y->c, scale, shift, rs, rb, bits); \
@@ -650,15 +693,18 @@ int launch_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
 
 extern "C" int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, const sfk_fmap* res,
                             const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
-                            uint8_t* relu_bits, sfk_stream_t stream) {
+                            uint8_t* relu_bits, float* out_sums, int32_t max_parts, int32_t* nparts_out,
+                            sfk_stream_t stream) {
   if (relu_bits && !relu) return SFK_ERR_INVALID;
+  if (out_sums && (max_parts <= 0 || !nparts_out)) return SFK_ERR_INVALID;
   if (!sfk_fmap_ok(y) || !sfk_fmap_ok(out) || !scale || !shift || !same_shape(y, out)) return SFK_ERR_INVALID;
   if (res && (!sfk_fmap_ok(res) || !same_shape(y, res))) return SFK_ERR_INVALID;
   if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return SFK_ERR_INVALID;
   if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res))) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return y->dtype == SFK_BF16 ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, s)
-                              : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, s);
+  return y->dtype == SFK_BF16
+             ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, out_sums, max_parts, nparts_out, s)
+             : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, out_sums, max_parts, nparts_out, s);
 }
 
 namespace {

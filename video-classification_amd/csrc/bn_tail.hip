@@ -1,8 +1,9 @@
 // The bottleneck tail  a -> conv_c (1x1x1) -> norm_c [-> + shortcut -> ReLU]  without the conv output in HBM
 // (include/sfk.h, sfk_bn_tail_fwd / sfk_bn_tail_bwd): the small per-layer algebra between the big kernels.
 //
-// What the big kernels deliver (ordinary sfk_conv_wgrad calls over `a` widened by a constant-1 channel):
-//     gram [c+V][c+V] fp32 : G = a^T a, row c = column sums g, element (c,c) = pixel count n
+// What the big kernels deliver:
+//     gram [c][c] fp32     : G = a^T a  (an ordinary sfk_conv_wgrad call with x = dy = a)
+//     a_sums [rows][c][2]  : partial column sums of a, left by the sfk_bn_apply pass that WROTE a; folded here into g = 1^T a
 //     r    [cout][c] fp32  : R = dz^T a;  s = sum dz arrives as the partial rows of the kernel that wrote dz
 // What this file computes from them -- everything is O(cout * c^2) or less, i.e. independent of the pixel count:
 //     forward : T = W G, batch mean / variance of y = a W^T per output channel, running statistics, scale / shift, and
@@ -22,10 +23,22 @@ template <typename D> __device__ __forceinline__ float wload(const void* w, int6
 constexpr int TF_CO = 8;      // output channels per block of the forward kernel
 constexpr int TF_MAXC = 512;  // widest conv_c input of the ResNet-50/101/152 SlowFast family (2048 / 4)
 
+// g[ci] = sum over the partial rows of a_sums[row][ci][0]: one wave per channel, double, fixed order
+__global__ __launch_bounds__(256) void bn_tail_fold_g_kernel(const float* __restrict__ parts, int nparts, int c, float* __restrict__ g) {
+  const int ci = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ci >= c) return;
+  double s = 0.0;
+  for (int p = lane; p < nparts; p += 64) s += (double)parts[((int64_t)p * c + ci) * 2];
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) s += __shfl_xor(s, sft);
+  if (lane == 0) g[ci] = (float)s;
+}
+
 // T[co][:] = W[co][:] G,  mean = W[co] . g / n,  var = W[co] Gc W[co]^T (Gc = the centred Gram matrix)  for TF_CO channels per
 // block; thread <-> column ci
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restrict__ gram, int c, int gld, const void* w,
+__global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restrict__ gram, const float* __restrict__ gvec,
+                                                          double n, int c, const void* w,
                                                           int cout, const float* gamma, const float* beta, float eps,
                                                           float momentum, float* running_mean, float* running_var,
                                                           int64_t* nbt, float* mean, float* invstd, float* scale,
@@ -36,12 +49,12 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
   __shared__ float acoef[TF_CO];
   const int co0 = blockIdx.x * TF_CO, tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0 && nbt) nbt[0] += 1;
-  const double n = (double)gram[(int64_t)c * gld + c], inv_n = 1.0 / n;
+  const double inv_n = 1.0 / n;
   for (int i = tid; i < TF_CO * c; i += 256) {
     const int o = i / c, j = i % c;
     wl[o][j] = co0 + o < cout ? wload<D>(w, (int64_t)(co0 + o) * c + j) : 0.f;
   }
-  for (int j = tid; j < c; j += 256) gl[j] = (float)((double)gram[(int64_t)c * gld + j] * inv_n);
+  for (int j = tid; j < c; j += 256) gl[j] = (float)((double)gvec[j] * inv_n);
   __syncthreads();
   constexpr int NR = TF_MAXC / 256;
   // acc = T = W G (the backward's operand).  The VARIANCE is not taken from it: E[y^2] - E[y]^2 cancels mean^2 / var digits of an
@@ -53,7 +66,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int ci = tid + 256 * r;
-    gbar[r] = ci < c ? (double)gram[(int64_t)c * gld + ci] * inv_n : 0.0;
+    gbar[r] = ci < c ? (double)gvec[ci] * inv_n : 0.0;
   }
 #pragma unroll
   for (int o = 0; o < TF_CO; ++o)
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int ci = tid + 256 * r;
-      gj[r] = ci < c ? gram[(int64_t)j * gld + ci] : 0.f;
+      gj[r] = ci < c ? gram[(int64_t)j * c + ci] : 0.f;
       gc[r] = (float)((double)gj[r] * inv_n - mj * gbar[r]);
     }
 #pragma unroll
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
       const int ci = tid + 256 * r;
       if (ci < c) {
         if (co0 + o < cout) t[(int64_t)(co0 + o) * c + ci] = acc[o][r];
-        p1[o] += (double)wl[o][ci] * (double)gram[(int64_t)c * gld + ci];
+        p1[o] += (double)wl[o][ci] * (double)gvec[ci];
         p2[o] += (double)accc[o][r] * (double)wl[o][ci];
       }
     }
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_tail_fwd_kernel(const float* __restric
 // one wave per output channel: sum dz*y = W[co] . R[co]; coefficients of dy = A dz + B y + C; dgamma, dbeta
 template <typename D>
 __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restrict__ rx, const float* __restrict__ parts,
-                                                           int nparts, const float* __restrict__ gram, int c, int gld,
+                                                           int nparts, double n, int c,
                                                            const void* w, int cout, const float* gamma,
                                                            const float* mean, const float* invstd, float* dgamma,
                                                            float* dbeta, float* coef) {
@@ -158,7 +171,6 @@ __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restri
     s += __shfl_xor(s, sft);
   }
   if (lane != 0) return;
-  const double n = (double)gram[(int64_t)c * gld + c];
   const double is = (double)invstd[co], mu = (double)mean[co];
   const double sxh = is * (sdy - mu * s);                 // sum dz * x_hat
   dgamma[co] += (float)sxh;
@@ -172,8 +184,8 @@ __global__ __launch_bounds__(256) void bn_tail_coef_kernel(const float* __restri
 
 // 32 x 32 (co, ci) tiles: dW += A R + B T + C g
 template <typename D>
-__device__ __forceinline__ void bn_tail_apply_part(int bx, int by, const float* __restrict__ rx, const float* __restrict__ gram,
-                                                   const float* __restrict__ t, int c, int gld, int cout,
+__device__ __forceinline__ void bn_tail_apply_part(int bx, int by, const float* __restrict__ rx, const float* __restrict__ gvec,
+                                                   const float* __restrict__ t, int c, int cout,
                                                    const float* __restrict__ coef, float* dw) {
   const int co0 = by * 32, ci0 = bx * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -183,7 +195,7 @@ __device__ __forceinline__ void bn_tail_apply_part(int bx, int by, const float* 
     if (co < cout && ci < c) {
       const float A = coef[co * 4], B = coef[co * 4 + 1], Cc = coef[co * 4 + 2];
       const int64_t idx = (int64_t)co * c + ci;
-      dw[idx] += A * rx[idx] + B * t[idx] + Cc * gram[(int64_t)c * gld + ci];
+      dw[idx] += A * rx[idx] + B * t[idx] + Cc * gvec[ci];
     }
   }
 }
@@ -235,63 +247,66 @@ __device__ __forceinline__ void bn_tail_bias_part(int bx, const void* w, int c, 
 
 // ONE launch for everything that only needs the coefficients: block ranges [dW tiles | m tiles | bias columns]
 template <typename D>
-__global__ __launch_bounds__(256) void bn_tail_post_kernel(const float* rx, const float* gram, const float* t, int c, int gld,
+__global__ __launch_bounds__(256) void bn_tail_post_kernel(const float* rx, const float* gvec, const float* t, int c,
                                                            const void* w, int cout, const float* coef, float* dw, D* m,
                                                            float* bias, int ax, int nap, int mx, int nm) {
   int b = blockIdx.x;
-  if (b < nap) { bn_tail_apply_part<D>(b % ax, b / ax, rx, gram, t, c, gld, cout, coef, dw); return; }
+  if (b < nap) { bn_tail_apply_part<D>(b % ax, b / ax, rx, gvec, t, c, cout, coef, dw); return; }
   b -= nap;
   if (b < nm) { bn_tail_m_part<D>(b % mx, b / mx, w, c, cout, coef, m); return; }
   bn_tail_bias_part<D>(b - nm, w, c, cout, coef, bias);
 }
 
-inline bool tail_args_ok(int c, int gld, int cout, int dtype) {
-  return c > 0 && cout > 0 && gld > c && (dtype == SFK_F32 || dtype == SFK_BF16);
+inline bool tail_args_ok(int c, int cout, int dtype) {
+  return c > 0 && cout > 0 && (dtype == SFK_F32 || dtype == SFK_BF16);
 }
 
 }  // namespace
 
-extern "C" int sfk_bn_tail_fwd(const float* gram, int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout,
+extern "C" int sfk_bn_tail_fwd(const float* gram, const float* a_sums, int32_t a_nparts, int64_t count, float* g, int32_t c,
+                               const void* w, int32_t w_dtype, int32_t cout,
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale, float* shift,
                                float* t, void* wd, sfk_stream_t stream) {
-  if (!gram || !w || !gamma || !beta || !mean || !invstd || !scale || !shift || !t) return SFK_ERR_INVALID;
-  if (!tail_args_ok(c, gld, cout, w_dtype) || (!running_mean) != (!running_var)) return SFK_ERR_INVALID;
+  if (!gram || !a_sums || a_nparts <= 0 || count <= 0 || !g || !w || !gamma || !beta || !mean || !invstd || !scale || !shift || !t)
+    return SFK_ERR_INVALID;
+  if (!tail_args_ok(c, cout, w_dtype) || (!running_mean) != (!running_var)) return SFK_ERR_INVALID;
   if (c > TF_MAXC) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_tail_fold_g_kernel, dim3((c + 3) / 4), dim3(256), 0, s, a_sums, a_nparts, c, g);
   const dim3 grid((cout + TF_CO - 1) / TF_CO), blk(256);
   if (w_dtype == SFK_BF16)
-    hipLaunchKernelGGL(bn_tail_fwd_kernel<bf16_t>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_tail_fwd_kernel<bf16_t>, grid, blk, 0, s, gram, g, (double)count, c, w, cout, gamma, beta, eps, momentum,
                        running_mean, running_var, nbt, mean, invstd, scale, shift, t, static_cast<bf16_t*>(wd));
   else
-    hipLaunchKernelGGL(bn_tail_fwd_kernel<float>, grid, blk, 0, s, gram, c, gld, w, cout, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_tail_fwd_kernel<float>, grid, blk, 0, s, gram, g, (double)count, c, w, cout, gamma, beta, eps, momentum,
                        running_mean, running_var, nbt, mean, invstd, scale, shift, t, static_cast<float*>(wd));
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
 
 template <typename D>
-static int tail_bwd_launch(const float* rx, const float* parts, int nparts, const float* gram, const float* t, int c, int gld, const void* w, int cout,
+static int tail_bwd_launch(const float* rx, const float* parts, int nparts, const float* g, int64_t count, const float* t, int c, const void* w, int cout,
                            const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                            float* dw, void* m, float* bias, float* coef, hipStream_t s) {
-  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, parts, nparts, gram, c, gld, w, cout, gamma, mean,
+  hipLaunchKernelGGL(bn_tail_coef_kernel<D>, dim3((cout + 3) / 4), dim3(256), 0, s, rx, parts, nparts, (double)count, c, w, cout, gamma, mean,
                      invstd, dgamma, dbeta, coef);
   const int ax = (c + 31) / 32, ay = (cout + 31) / 32, mx = (c + 15) / 16, nb = (c + 15) / 16;
-  hipLaunchKernelGGL(bn_tail_post_kernel<D>, dim3(ax * ay + mx * mx + nb), dim3(256), 0, s, rx, gram, t, c, gld, w, cout, coef, dw,
+  hipLaunchKernelGGL(bn_tail_post_kernel<D>, dim3(ax * ay + mx * mx + nb), dim3(256), 0, s, rx, g, t, c, w, cout, coef, dw,
                      static_cast<D*>(m), bias, ax, ax * ay, mx, mx * mx);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
 
-extern "C" int sfk_bn_tail_bwd(const float* rx, const float* parts, int32_t nparts, const float* gram, const float* t,
-                               int32_t c, int32_t gld, const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
+extern "C" int sfk_bn_tail_bwd(const float* rx, const float* parts, int32_t nparts, const float* g, int64_t count, const float* t,
+                               int32_t c, const void* w, int32_t w_dtype, int32_t cout, const float* gamma, const float* mean, const float* invstd,
                                float* dgamma, float* dbeta, float* dw, void* m, float* bias, float* coef,
                                sfk_stream_t stream) {
-  if (!rx || !parts || nparts <= 0 || !gram || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !m || !bias || !coef)
+  if (!rx || !parts || nparts <= 0 || !g || count <= 0 || !t || !w || !gamma || !mean || !invstd || !dgamma || !dbeta || !dw || !m || !bias || !coef)
     return SFK_ERR_INVALID;
-  if (!tail_args_ok(c, gld, cout, w_dtype)) return SFK_ERR_INVALID;
+  if (!tail_args_ok(c, cout, w_dtype)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return w_dtype == SFK_BF16
-             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s)
-             : tail_bwd_launch<float>(rx, parts, nparts, gram, t, c, gld, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s);
+             ? tail_bwd_launch<bf16_t>(rx, parts, nparts, g, count, t, c, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s)
+             : tail_bwd_launch<float>(rx, parts, nparts, g, count, t, c, w, cout, gamma, mean, invstd, dgamma, dbeta, dw, m, bias, coef, s);
 }

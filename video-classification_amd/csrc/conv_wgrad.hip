@@ -773,6 +773,7 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
                     d->taps[0].dt == 0 && d->taps[0].dh == 0 && d->taps[0].dw == 0 && d->gs[0] == 1 && d->gs[1] == 1 && d->gs[2] == 1 &&
                     (sfk_tune().wgrad_wide_co & 4);
   if (gram && cols <= 32) return launch_cfg<T, 32, 32, 4, true>(k, d, s, dry);
+  if (gram && cols <= 64) return launch_cfg<T, 64, 64, 2, true>(k, d, s, dry);
   if (gram && cols > 64 && cols <= 128) return launch_cfg<T, 128, 128, 1, true>(k, d, s, dry);
   if (cols <= 32) {
     if (d->cout <= 32) return launch_cfg<T, 32, 32, 4>(k, d, s, dry);

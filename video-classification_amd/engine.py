@@ -63,21 +63,6 @@ class _UnitRec:
     shift: torch.Tensor
 
 
-def _cu_masked_stream(device, ncu: int):
-    """a HIP stream whose kernels only run on `ncu` compute units (hipExtStreamCreateWithCUMask), wrapped for torch"""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = 8                                   # 256 CUs
-    mask = (ctypes.c_uint32 * words)()
-    for i in range(min(ncu, 32 * words)):
-        mask[i // 32] |= 1 << (i % 32)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
-    assert rc == 0, f"hipExtStreamCreateWithCUMask: {rc}"
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
 class Wait:
     """Schedule marker: stream of pathway `lane` must wait for everything issued so far on pathway `on`.
     A no-op when the schedule runs on a single stream (stream order already implies it)."""
@@ -681,34 +666,34 @@ class Engine:
         """norm_b apply -> [Gram matrix -> statistics] -> conv_c with BatchNorm + shortcut + ReLU in its epilogue"""
         n, c4, C = yb.n, Lc.eg.cin, Lc.eg.cout
         V = self.kvec
-        gld = c4 + V
         esz = 2 if self.dtype == torch.bfloat16 else 4
-        # conv_c's input lives widened by one channel group whose first channel is the constant 1 (set here, once: kernels
-        # only ever write the c4 data channels); the tag carries the geometry so no other plan's layout shares the buffer
-        full = self._fmap(f"a.{tag}.b.w{n}x{yb.t}x{yb.h}x{yb.w}", n, yb.t, yb.h, yb.w, gld)
-        full.view5()[..., c4:] = 0
-        full.view5()[..., c4] = 1
-        ab = full.channels(0, c4)
-        self._apply(pl, yb, sb, hb, None, None, None, True, ab)
+        ab = self._fmap(f"a.{tag}.b", n, yb.t, yb.h, yb.w, c4)
         scale = self._buf(f"scale.{tag}.c", C, torch.float32)
         shift = self._buf(f"shift.{tag}.c", C, torch.float32)
         gamma, beta = self._pslice(Lc.g_off, C), self._pslice(Lc.b_off, C)
         w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
         tail = None
         if train:
-            gram = self._tail_zero("f", gld * gld)
+            # norm_b apply writes a_b AND leaves its column sums g = 1^T a_b as partial rows (no constant-1 channel beside a_b:
+            # on the fast pathway's 8 .. 32-channel maps the widened records doubled .. 1.25x-ed every pass over a_b)
+            asums = self._buf(f"asums.{tag}", self.max_parts * c4 * 2, torch.float32)
+            run, a_np = self.be.bn_apply(yb, sb, hb, None, None, None, True, ab, out_sums=asums, max_parts=self.max_parts)
+            pl.fwd.append(run, kind="bn_apply", bytes=float(yb.pixels * c4 * esz * 2))
+            gram = self._tail_zero("f", c4 * c4)
             lane = pl.fwd.cur_lane
-            self._ws_wgrad(pl.fwd, WgradPass(full, full, (1, 1, 1), self.TAP0, gram, 1, gld, gld), f"f{lane}",
-                           kind="conv_wgrad", layer=Lc.cb.conv_key + ":gram", cout=gld,
-                           flops=2.0 * full.pixels * gld * gld, bytes=float(esz * full.pixels * gld + 4 * gld * gld))
+            self._ws_wgrad(pl.fwd, WgradPass(ab, ab, (1, 1, 1), self.TAP0, gram, 1, c4, c4), f"f{lane}",
+                           kind="conv_wgrad", layer=Lc.cb.conv_key + ":gram", cout=c4,
+                           flops=2.0 * ab.pixels * c4 * c4, bytes=float(esz * ab.pixels * c4 + 4 * c4 * c4))
             mean = self._buf(f"mean.{tag}.c", C, torch.float32)
             invstd = self._buf(f"invstd.{tag}.c", C, torch.float32)
             t = self._buf(f"tailT.{tag}", C * c4, torch.float32)
+            gvec = self._buf(f"tailg.{tag}", c4, torch.float32)
             wd = self._buf(f"tailWd.{tag}", C * c4)       # (A W)^T, A = gamma * invstd: the backward's first dgrad filter
-            pl.fwd.append(self.be.bn_tail_fwd(gram, c4, gld, w, C, gamma, beta, self.spec.bn_eps, self.spec.bn_momentum,
-                                              Lc.rm, Lc.rv, Lc.nbt, mean, invstd, scale, shift, t, wd))
-            tail = dict(full=full, ab=ab, gram=gram, t=t, mean=mean, invstd=invstd, gld=gld, wd=wd)
+            pl.fwd.append(self.be.bn_tail_fwd(gram, asums, a_np, ab.pixels, gvec, c4, w, C, gamma, beta, self.spec.bn_eps,
+                                              self.spec.bn_momentum, Lc.rm, Lc.rv, Lc.nbt, mean, invstd, scale, shift, t, wd))
+            tail = dict(ab=ab, g=gvec, count=ab.pixels, t=t, mean=mean, invstd=invstd, wd=wd)
         else:
+            self._apply(pl, yb, sb, hb, None, None, None, True, ab)
             pl.fwd.append(self.be.bn_eval_coeffs(gamma, beta, Lc.rm, Lc.rv, self.spec.bn_eps, C, scale, shift))
         bits = self._buf(f"relubits.{tag}", out.pixels * (C // V), torch.uint8) if train else None
         cp = ConvPass(ab, out, (ab.t, ab.h, ab.w), (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, w, 1, c4, C,
@@ -730,7 +715,7 @@ class Engine:
                     Lc = self._layers[blk.conv_c.conv_key]
                     if self._tail_ok(Lc):
                         c4, C = Lc.eg.cin, Lc.eg.cout
-                        nf += round_up((c4 + V) ** 2, 64)
+                        nf += round_up(c4 ** 2, 64)
                         nb += round_up(C * c4, 64)
         self._tailz = {"f": self._buf("tailz.f", nf, torch.float32)[:nf] if (train and nf) else None,
                        "b": self._buf("tailz.b", nb, torch.float32)[:nb] if (train and nb) else None}
@@ -744,8 +729,8 @@ class Engine:
     def _tail_bwd(self, pl, Lc: _Layer, tail: dict, d_out: FMap, dab: FMap, tag: str, dz_parts):
         """dz (in d_out) -> dgamma, dbeta, dW of conv_c / norm_c and d(a_b) in dab, without y_c or dy_c:
         R = dz^T a_b, s = sum dz as the partial rows dz_parts = (rows, count) of the kernel that wrote dz, the small algebra of sfk_bn_tail_bwd, then  d(a_b) = dz (A W) + a_b (W^T B W) + C W."""
-        c4, C, gld = Lc.eg.cin, Lc.eg.cout, tail["gld"]
-        full, ab = tail["full"], tail["ab"]
+        c4, C = Lc.eg.cin, Lc.eg.cout
+        ab = tail["ab"]
         esz = 2 if self.dtype == torch.bfloat16 else 4
         w = self.S[Lc.w_off:Lc.w_off + Lc.w_numel]
         r = self._tail_zero("b", C * c4)
@@ -784,7 +769,7 @@ class Engine:
         bias = self._buf(f"tailbias.{tag}", c4, torch.float32)
         coef = self._buf(f"tailcoef.{tag}", C * 4, torch.float32)
         m = self._buf(f"tailM.{tag}", c4 * c4)             # W^T diag(B) W, the filter of the second data-gradient pass
-        pl.bwd.append(self.be.bn_tail_bwd(r, dz_parts[0], dz_parts[1], tail["gram"], tail["t"], c4, gld, w, C, self._pslice(Lc.g_off, C), tail["mean"],
+        pl.bwd.append(self.be.bn_tail_bwd(r, dz_parts[0], dz_parts[1], tail["g"], tail["count"], tail["t"], c4, w, C, self._pslice(Lc.g_off, C), tail["mean"],
                                           tail["invstd"], self._gslice(Lc.g_off, C), self._gslice(Lc.b_off, C),
                                           self._gslice(Lc.w_off, Lc.w_numel), m, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
@@ -1116,10 +1101,6 @@ class Engine:
             return [main]
         if self._side is None:
             self._side = [torch.cuda.Stream(self.device) for _ in range(self.NLANES - 1)]
-            ncu = int(os.environ.get("SFK_WG_CUS", "0"))
-            if ncu > 0:      # EXPERIMENT: the filter-gradient lanes on streams restricted to the first `ncu` CUs of the mask
-                for lane in (2, 3):
-                    self._side[lane - 1] = _cu_masked_stream(self.device, ncu)
         return [main] + self._side
 
     def _run_lanes(self, ops: "OpList", begin: int = 0, end: Optional[int] = None):
