@@ -69,10 +69,12 @@ __device__ __forceinline__ void load_coef(float (&dst)[VEC], const float* src, i
   for (int i = 0; i < VEC; ++i) dst[i] = src[cg * VEC + i];
 }
 
-// block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group: rows_b = 256 / cgs_b row
-// lanes per group.  Two levels in a fixed order (deterministic): R2 row lanes each add rows r, r + R2, ... in order, then row
-// lane 0 adds the R2 partial sums.  (One level -- row lane 0 walking all rows_b rows -- was a serial tail of up to 256 x 16
-// LDS reads on the 8 .. 32-channel maps of the fast pathway: 5 .. 8 us of a 17 us kernel.)
+// block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group.  The threads' values
+// form a matrix [rows_b][W] in LDS, W = cgs_b * 2 * VEC columns (the layout of one partial row); a thread then owns ONE column
+// and 1 / G of the rows (G = 256 / W row groups, in a fixed order: deterministic), and W threads add the G group sums.  One
+// accumulator register per thread: the callers sit at their VGPR caps (bn_pool_bwd_kernel: 128), and the first version -- row
+// lane 0 of every channel group walking all rows_b rows of 2 * VEC values -- was a serial tail of up to 256 x 16 LDS reads on
+// the 8 .. 32-channel maps of the fast pathway (5 .. 8 us of a 17 us kernel).
 template <int VEC>
 __device__ __forceinline__ void block_reduce_store(const ChanMap& cm, int cgs, const float (&a)[VEC],
                                                    const float (&b)[VEC], float* partials, int c) {
@@ -85,40 +87,29 @@ __device__ __forceinline__ void block_reduce_store(const ChanMap& cm, int cgs, c
   }
   __syncthreads();
   const int cgs_b = cgs < 256 ? cgs : 256;
-  const int ty = threadIdx.x / cgs_b, tx = threadIdx.x % cgs_b;
-  const int R2 = cm.rows_b >= 64 ? 16 : (cm.rows_b >= 16 ? 4 : 1);     // second-level fan-in
-  float sa[VEC], sb[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-  const bool lvl1 = ty < R2 && ty < cm.rows_b && cm.cg < cgs;
-  if (lvl1) {
-    for (int r = ty; r < cm.rows_b; r += R2) {
-      const float* o = red + (r * cgs_b + tx) * 2 * VEC;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { sa[i] += o[2 * i]; sb[i] += o[2 * i + 1]; }
+  const int W = cgs_b * 2 * VEC, rows = cm.rows_b, tid = threadIdx.x;
+  float* out = partials + (int64_t)blockIdx.x * c * 2 + (int64_t)blockIdx.y * 256 * VEC * 2;
+  const int ncol = (cgs - (int)blockIdx.y * 256 < cgs_b ? cgs - (int)blockIdx.y * 256 : cgs_b) * 2 * VEC;   // columns that exist
+  if (W >= 256) {                 // rows <= 16: a thread adds its column(s) over all rows
+    for (int col = tid; col < W; col += 256) {
+      float sacc = 0.f;
+      for (int r = 0; r < rows; ++r) sacc += red[r * W + col];
+      if (col < ncol) out[col] = sacc;
     }
+    return;
   }
-  if (R2 > 1) {
-    __syncthreads();                     // every level-1 read of `red` is done before it is overwritten
-    if (lvl1) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { mine[2 * i] = sa[i]; mine[2 * i + 1] = sb[i]; }
-    }
-    __syncthreads();
-    if (ty == 0 && cm.cg < cgs) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-      for (int r = 0; r < R2 && r < cm.rows_b; ++r) {
-        const float* o = red + (r * cgs_b + tx) * 2 * VEC;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { sa[i] += o[2 * i]; sb[i] += o[2 * i + 1]; }
-      }
-    }
-  }
-  if (ty == 0 && cm.cg < cgs) {
-    float* out = partials + ((int64_t)blockIdx.x * c + cm.cg * VEC) * 2;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { out[2 * i] = sa[i]; out[2 * i + 1] = sb[i]; }
+  const int G = 256 / W;          // >= 2 row groups (W <= 128)
+  const int g = tid / W, col = tid - g * W;
+  float sacc = 0.f;
+  if (g < G)
+    for (int r = g; r < rows; r += G) sacc += red[r * W + col];
+  __syncthreads();                // every first-level read is done before `red` is overwritten
+  if (g < G) red[g * W + col] = sacc;
+  __syncthreads();
+  if (tid < W) {
+    sacc = 0.f;
+    for (int q = 0; q < G; ++q) sacc += red[q * W + tid];
+    if (tid < ncol) out[tid] = sacc;
   }
 }
 
