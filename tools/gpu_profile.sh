@@ -29,5 +29,7 @@ c = json.load(open("gpurun_out/class_stats.json"))
 for k, v in list(c["classes"].items())[:12]: print(f"{k:16s} {v}")
 print(c.get("roofline_check"))
 PY
+KT=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -n 1)
+python tools/trace_outliers.py "$KT" > gpurun_out/trace_outliers.txt 2>&1; head -n 25 gpurun_out/trace_outliers.txt
 find gpurun_out/prof -name "*kernel_trace.csv" -size +40M -delete
 if [ "${TRAFFIC:-0}" = "1" ]; then bash tools/gpu_traffic.sh; fi
