@@ -235,9 +235,10 @@ int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, float* dw, sf
 /* Training forward, step 1: reduce `nparts` partial (sum, sumsq) rows -> batch mean / biased var; writes
  * mean, invstd, the fused scale = gamma*invstd and shift = beta - mean*scale, and updates
  * running_mean/var (unbiased var, momentum) and num_batches_tracked exactly as nn.BatchNorm3d does.
- * workspace: NULL, or [SFK_BN_FOLD_ROWS][c][2] floats of scratch: with it, more than 2*SFK_BN_FOLD_ROWS rows are
- * first folded down by a grid of workgroups (a conv over a large map leaves thousands of rows). Either way the sums
- * are accumulated in double in a fixed order (deterministic). */
+ * workspace: NULL, or [SFK_BN_FOLD_ROWS][c][2] floats of scratch: with it, more than 4096 rows (the stems of the metric
+ * geometry leave 50,176) are first folded down by a grid of workgroups; up to that a 256-thread block per channel pair
+ * folds the rows in the finalize launch itself.  Either way the sums are accumulated in double in a fixed order
+ * (deterministic).  c must be even (SFK_ERR_UNSUPPORTED otherwise; feature maps have c % 4 == 0). */
 int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,

@@ -175,10 +175,15 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
   }
 }
 
-// returns the rows left to fold (in `*rows_out`) and where they are; launches the first level when it pays
+// returns the rows left to fold (in `*rows_out`) and where they are; launches the first level when it pays: the finalize
+// kernels give a whole 256-thread block to a channel pair, so up to SFK_BN_DIRECT_ROWS rows (16 loads per thread, all in
+// flight at once) are folded there and the step's ~170 BatchNorms do without this launch (5.6 us each on the chain:
+// finalize 10 -> 4..5 us).  Not for the widest tables (3,136 rows x 256 channels = 6.4 MB read through 16-byte segments of
+// 64-byte sectors: 12.4 us in one launch against 10 in two)
+constexpr int SFK_BN_DIRECT_ROWS = 4096;
 inline const float* fold_partials(const float* partials, int nparts, int c, float* workspace, int* rows_out,
                                   hipStream_t s) {
-  if (!workspace || nparts <= 2 * SFK_BN_FOLD_ROWS) {
+  if (!workspace || (nparts <= SFK_BN_DIRECT_ROWS && (int64_t)nparts * c <= SFK_BN_DIRECT_ROWS * 128)) {
     *rows_out = nparts;
     return partials;
   }
@@ -191,22 +196,38 @@ inline const float* fold_partials(const float* partials, int nparts, int c, floa
   return workspace;
 }
 
-// one wave per channel: lanes stride over the partial rows, butterfly in double
-__device__ __forceinline__ void wave_sum_partials(const float* partials, int nparts, int c, int ch, double& s1,
-                                                  double& s2) {
-  const int lane = threadIdx.x & 63;
-  s1 = 0.0;
-  s2 = 0.0;
-  for (int p = lane; p < nparts; p += 64) {
-    const float2 v = *reinterpret_cast<const float2*>(partials + ((int64_t)p * c + ch) * 2);
-    s1 += (double)v.x;
-    s2 += (double)v.y;
+// one 256-thread block per channel PAIR: thread t folds rows t, t + 256, ... (one 16-byte load per row: (s1, s2) of both
+// channels) in double, then a fixed-order tree over the block -- deterministic.  On return threads 0 and 1 hold the sums of
+// channels ch0 and ch0 + 1.
+__device__ __forceinline__ void block_sum_partials(const float* __restrict__ partials, int nparts, int c, int ch0,
+                                                   double& s1, double& s2) {
+  __shared__ double red[4][256];
+  const int tid = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  const float* base = partials + (int64_t)ch0 * 2;
+#pragma unroll 4
+  for (int p = tid; p < nparts; p += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)p * c * 2);
+    a0 += (double)v.x;
+    a1 += (double)v.y;
+    b0 += (double)v.z;
+    b1 += (double)v.w;
   }
+  red[0][tid] = a0;
+  red[1][tid] = a1;
+  red[2][tid] = b0;
+  red[3][tid] = b1;
+  __syncthreads();
 #pragma unroll
-  for (int sft = 1; sft < 64; sft <<= 1) {
-    s1 += __shfl_xor(s1, sft);
-    s2 += __shfl_xor(s2, sft);
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + st];
+    }
+    __syncthreads();
   }
+  s1 = red[(tid & 1) * 2][0];
+  s2 = red[(tid & 1) * 2 + 1][0];
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int nparts, int c, double count,
@@ -214,12 +235,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials,
                                                           float momentum, float* running_mean, float* running_var,
                                                           int64_t* nbt, float* mean, float* invstd, float* scale,
                                                           float* shift) {
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ch = blockIdx.x * 2 + (threadIdx.x & 1);         // c is a multiple of 2 (checked by the callers)
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
-  if (ch >= c) return;
   double s1, s2;
-  wave_sum_partials(partials, nparts, c, ch, s1, s2);
-  if ((threadIdx.x & 63) != 0) return;
+  block_sum_partials(partials, nparts, c, blockIdx.x * 2, s1, s2);
+  if (threadIdx.x > 1) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -399,11 +419,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
                                                               double count, const float* gamma,
                                                               const float* invstd, float* dgamma, float* dbeta,
                                                               float* coef) {
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ch >= c) return;
+  const int ch = blockIdx.x * 2 + (threadIdx.x & 1);
   double s1, s2;
-  wave_sum_partials(partials, nparts, c, ch, s1, s2);
-  if ((threadIdx.x & 63) != 0) return;
+  block_sum_partials(partials, nparts, c, blockIdx.x * 2, s1, s2);
+  if (threadIdx.x > 1) return;
   if (dgamma) dgamma[ch] += (float)s2;
   if (dbeta) dbeta[ch] += (float)s1;
   coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
@@ -626,9 +645,10 @@ extern "C" int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c,
   if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift)
     return SFK_ERR_INVALID;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SFK_ERR_INVALID;
+  if (c & 1) return SFK_ERR_UNSUPPORTED;           // a block folds a channel PAIR (16-byte loads); maps have c % 4 == 0
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, s, partials,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c / 2), dim3(256), 0, s, partials,
                      nparts, c, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
                      num_batches_tracked, mean, invstd, scale, shift);
   SFK_CHECK_LAUNCH();
@@ -787,9 +807,10 @@ extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_
                                    const float* invstd, float* dgamma, float* dbeta, float* coef,
                                    float* workspace, sfk_stream_t stream) {
   if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !invstd || !coef) return SFK_ERR_INVALID;
+  if (c & 1) return SFK_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, s,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 2), dim3(256), 0, s,
                      partials, nparts, c, (double)count, gamma, invstd, dgamma, dbeta, coef);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
