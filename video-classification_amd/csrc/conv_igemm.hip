@@ -183,7 +183,7 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
                                                 int wm, int wn, int lane, int tid) {
   const int l15 = lane & 15, g = lane >> 4;
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
-  const bool bitmode = k.bn_y == nullptr;     // mask = the output ReLU bitmap k.obits, only sum dz is left (fused block tail)
+  constexpr bool bitmode = false;             // (bn_y == NULL, the bitmap flavour, is epilogue_bits_sum: EPI == 5)
   const bool has_msrc = k.bn_mask != nullptr;
   const bool relu_y = k.bn_relu && !has_msrc && !bitmode;       // mask from y * scale + shift > 0
   const int co_w = nt * BN + wn * (BN / WN);
@@ -303,6 +303,98 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
       float* o = k.bn_parts + ((int64_t)mt * k.cout + co) * 2;
       o[0] = a;
       o[1] = b;
+    }
+  }
+}
+
+// The bitmap flavour of the above (bnb.y_bn == NULL: the data gradient that finishes the output gradient of a block with a
+// fused tail -- dX = (dX + dY W^T) * bit, partial rows (sum dz, 0)) with ALL of a lane's loads in flight at once: the old
+// rows and the bitmap bytes of its FM x FN/2 sixteen-byte stores (40 VGPRs beside the accumulators).  The general routine
+// keeps two pixel rows in flight (it also carries y_bn, the mask source and four coefficient vectors), i.e. FM / 2 x FN / 2
+// serial round trips per tile -- on the fast pathway's conv_a layers, whose K loop is 1..6 steps, that WAS the kernel:
+// 156 us for a pass whose bytes take 59.
+template <int FM, int FN, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_bits_sum(const ConvK& k, const f32x4 (&acc)[FN][FM], float* red, int mt, int nt,
+                                                  int wm, int wn, int lane, int tid) {
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
+  const int co_w = nt * BN + wn * (BN / WN);
+  const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
+  const __amdgpu_buffer_rsrc_t r_b = sfk_make_rsrc(k.obits, k.obits_bytes);
+  int64_t plin[FM];
+  bool rok[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m0 = mt * BM + wm * (BM / WM) + 16 * j + l15;
+    rok[j] = m0 < k.M;
+    const int m = rok[j] ? m0 : k.M - 1;
+    if (k.lin_out) {
+      plin[j] = m;
+    } else {
+      uint32_t q1, rw_, q2, rh_, n_, rt_;
+      k.drw.divmod((uint32_t)m, q1, rw_);
+      k.drh.divmod(q1, q2, rh_);
+      k.drt.divmod(q2, n_, rt_);
+      const int to = (int)rt_ * k.ost + k.oot, ho = (int)rh_ * k.osh + k.ooh, wo = (int)rw_ * k.osw + k.oow;
+      plin[j] = (((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo;
+    }
+  }
+  bf16x8 oldv[FN / 2][FM];
+  uint32_t mbyte[FN / 2][FM];
+#pragma unroll
+  for (int p = 0; p < FN; p += 2) {
+    const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
+    const int cc = co < k.cout ? co : 0;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      oldv[p / 2][j] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_old, (uint32_t)((plin[j] * k.yld + k.yoff + cc) * 2)));
+      mbyte[p / 2][j] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r_b, (int)(plin[j] * (k.cout >> 3) + (cc >> 3)), 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < FN; p += 2) {
+    const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
+    const bool cok = co < k.cout;
+    float s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      float v[8] = {acc[p][j][0], acc[p][j][1], acc[p][j][2], acc[p][j][3],
+                    acc[p + 1][j][0], acc[p + 1][j][1], acc[p + 1][j][2], acc[p + 1][j][3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) swap16(v[e], v[4 + e]);
+      const bool live = rok[j] && cok;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float vv = v[e] + (float)oldv[p / 2][j][e];             // (no accumulate: zero-sized resource, + 0)
+        const bf16_t dzb = (bf16_t)(((mbyte[p / 2][j] >> e) & 1u) ? vv : 0.f);   // the value as it is STORED, masked
+        o[e] = dzb;
+        s1[e] += live ? (float)dzb : 0.f;
+      }
+      if (live) *reinterpret_cast<bf16x8*>(yp + plin[j] * k.yld + k.yoff + co) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = row16_sum(s1[e]);
+      if (l15 == 15) {
+        const int col = wn * (BN / WN) + 16 * (p + (g & 1)) + 8 * (g >> 1) + e;
+        red[(wm * BN + col) * 2 + 0] = a;
+        red[(wm * BN + col) * 2 + 1] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    const int co = nt * BN + tid;
+    if (co < k.cout) {
+      float a = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WM; ++w_) a += red[(w_ * BN + tid) * 2 + 0];
+      float* o = k.bn_parts + ((int64_t)mt * k.cout + co) * 2;
+      o[0] = a;
+      o[1] = 0.f;
     }
   }
 }
@@ -643,7 +735,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvK& k, const f32x4 (&acc
   }
 }
 
-// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb), 2 output ReLU bitmap (out_relu_bits), 3 fused output
+// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb; 5 = its bitmap flavour), 2 output ReLU bitmap (out_relu_bits), 3 fused output
 // transform (sfk_conv_epilogue) -- own
 // instantiations: the extra epilogue state must not cost the plain kernel registers (the 256x128 tile sits at 128 VGPRs)
 template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, int EPI = 0>
@@ -831,9 +923,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
 
   // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
-  if constexpr (EPI == 1 && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: its own instantiation
+  if constexpr ((EPI == 1 || EPI == 5) && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: own instantiations
     __syncthreads();        // the partial sums go through LDS that aliases the ring
-    epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    if constexpr (EPI == 5) epilogue_bits_sum<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    else epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
   if constexpr (EPI == 3) {
@@ -1056,8 +1149,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
   __syncthreads();
 
   // ---- epilogue
-  if constexpr (EPI == 1) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
-    epilogue_bn_bwd<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+  if constexpr (EPI == 1 || EPI == 5) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
+    if constexpr (EPI == 5) epilogue_bits_sum<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    else epilogue_bn_bwd<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
   if constexpr (EPI == 3) {
@@ -1229,8 +1323,9 @@ int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
-  if (k.bn_parts) {
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);   // (pick_tile: never 256 x 128)
+  if (k.bn_parts) {          // (pick_tile: never 256 x 128); 5 = the bitmap flavour (mask = out_relu_bits, sums of dz only)
+    if (k.bn_y == nullptr) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 5>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
@@ -1317,7 +1412,11 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   if (ts.dma) return launch_dma(k, ts.bm, grid, s, ts.bn);
   if (k.bn_parts) {          // fused BatchNorm-backward reduce (bf16, cout > 16: tiles of 32..128 output channels)
     if constexpr (sizeof(T) == 2) {
-      if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
+      if (k.bn_y == nullptr) {      // the bitmap flavour
+        if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 5>), grid, block, 0, s, k);
+        else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 5>), grid, block, 0, s, k);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 5>), grid, block, 0, s, k);
+      } else if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
       else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 1>), grid, block, 0, s, k);
       else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 1>), grid, block, 0, s, k);
       SFK_CHECK_LAUNCH();
