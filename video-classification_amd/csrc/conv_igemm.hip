@@ -46,6 +46,7 @@ struct ConvK {
   FastDiv dkct;   // K-steps per tap of the uniform walk (cin / 32)
   uint32_t xbytes, wbytes;   // extents of the two buffer resources
   uint32_t ybytes, ep_rbytes; // ... and of y / the shortcut map (fused epilogue: branch-free loads)
+  int ybig;                   // y holds 4 GiB or more: the plain epilogue's += reads it through 64-bit pointers
   uint32_t bn_ybytes, bn_mbytes, obits_bytes;   // ... and of the fused BatchNorm-backward epilogue's operands
   sfk_tap taps[SFK_MAX_TAPS];
 };
@@ -527,13 +528,26 @@ __device__ __forceinline__ void epilogue_fused(const ConvK& k, const f32x4 (&acc
       const int co = co_w + 16 * i + 4 * g;
       const bool cok = co < k.cout;
       const int cc = cok ? co : 0;
+      // coefficients: one 16-byte buffer load per vector, nothing under a branch (see the 16-byte path above: a conditional
+      // load makes hipcc drain vmcnt behind it -- sixteen serial round trips per tile here, and the += + bias pass of the
+      // fast pathway's 8-channel maps, a ONE K-step layer, took 85 us for 154 MB)
       float sc[4], sh[4], rs[4], rh[4];
+      {
+        const uint32_t cb = (uint32_t)cc * 4u, nb = (uint32_t)k.cout * 4u;
+        const bool has_sc = k.ep_scale != nullptr, has_rs = rp && k.ep_rscale;
+        const uint4 a0 = sfk_buffer_load16(sfk_make_rsrc(k.ep_scale, has_sc ? nb : 0u), cb);
+        const uint4 b0 = sfk_buffer_load16(sfk_make_rsrc(k.ep_shift, k.ep_shift ? nb : 0u), cb);
+        const uint4 c0 = sfk_buffer_load16(sfk_make_rsrc(k.ep_rscale, has_rs ? nb : 0u), cb);
+        const uint4 d0 = sfk_buffer_load16(sfk_make_rsrc(k.ep_rshift, (rp && k.ep_rshift) ? nb : 0u), cb);
+        const uint32_t av[4] = {a0.x, a0.y, a0.z, a0.w}, bv[4] = {b0.x, b0.y, b0.z, b0.w};
+        const uint32_t cv[4] = {c0.x, c0.y, c0.z, c0.w}, dv[4] = {d0.x, d0.y, d0.z, d0.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sc[e] = k.ep_scale ? k.ep_scale[cc + e] : 1.f;
-        sh[e] = k.ep_shift ? k.ep_shift[cc + e] : 0.f;
-        rs[e] = (rp && k.ep_rscale) ? k.ep_rscale[cc + e] : 1.f;
-        rh[e] = (rp && k.ep_rshift) ? k.ep_rshift[cc + e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          sc[e] = has_sc ? __uint_as_float(av[e]) : 1.f;
+          sh[e] = __uint_as_float(bv[e]);
+          rs[e] = has_rs ? __uint_as_float(cv[e]) : 1.f;
+          rh[e] = __uint_as_float(dv[e]);
+        }
       }
       float oldv[FM][4], resv[FM][4];
       if constexpr (sizeof(T) == 2) {
@@ -614,14 +628,33 @@ __device__ __forceinline__ void epilogue_plain(const ConvK& k, const f32x4 (&acc
       poffs[j] = ((((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo) * k.yld + k.yoff;
     }
   }
+  // old rows of a += pass: BRANCH-FREE buffer loads, all in flight before the first store (rows past M re-read the last
+  // row, channels past cout channel 0, a plain pass reads zeros from a zero-sized resource -- nothing of those is stored):
+  // with the loads under `if (m < M)` hipcc drains vmcnt behind each row, FM serial round trips per tile
   bf16x8 oldv[FM][(FN + 1) / 2];
-  if (wide && k.accumulate) {
+  if constexpr (sizeof(T) == 2) {
+    if (wide && k.accumulate && k.ybig) {            // a map of 4 GiB or more: 64-bit pointers (rare; the slow way)
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
-      if (m < k.M) {
+      for (int j = 0; j < FM; ++j) {
+        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+        if (m < k.M) {
 #pragma unroll
-        for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
+          for (int i = 0; i < FN; i += 2) oldv[j][i / 2] = load8_old(yp + poffs[j], co_w + 16 * i, k.cout, g);
+        }
+      }
+    } else if (wide) {
+      const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
+      const int64_t plast = k.lin_out ? ((int64_t)(k.M - 1) * k.yld + k.yoff) : poffs[0];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = mt * BM + wm * (BM / WM) + 16 * j + l15;
+        // (gathered output rows past M decode to some in-range pixel of the map already: poffs[j] is a valid address)
+        const int64_t po = (k.lin_out && m >= k.M) ? plast : poffs[j];
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) {
+          const int co = co_w + 16 * i + 16 * (g & 1) + 8 * (g >> 1);
+          oldv[j][i / 2] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_old, (uint32_t)((po + (co < k.cout ? co : 0)) * 2)));
+        }
       }
     }
   }
@@ -1233,7 +1266,9 @@ inline bool pw_plain_route(const sfk_conv_desc* d) {
   // the streaming kernel reads the old rows of a += pass through a 32-bit buffer resource (validate() bounds y only for
   // fused epilogues): maps of 4 GiB and more stay on the implicit GEMM, whose epilogue uses 64-bit pointers
   if (sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64) return false;
-  return (d->cout == 64 && d->cin == 64) || (d->cout == 128 && d->cin == 128);
+  // (128 -> 320: the data gradient of slow res3's first conv_a into the concatenated 256 + 64-channel input gradient -- an
+  // output-heavy pass, 514 MB written for 205 read: 220 us on the 2.5-tile-wide implicit GEMM)
+  return (d->cout == 64 && d->cin == 64) || (d->cout == 128 && d->cin == 128) || (d->cout == 320 && d->cin == 128 && !d->accumulate && !d->ep.shift);
 }
 // rows of the streaming data-gradient kernel (accumulate + bitmap mask + column sums), 0 when the pass is not one of its
 inline int pw_dgrad_rows(const sfk_conv_desc* d) {
@@ -1379,6 +1414,7 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
   k.ep_res = d->ep.res.ptr; k.ep_rld = d->ep.res.ld; k.ep_roff = d->ep.res.c_off;
   k.ep_relu = d->ep.relu; k.ep_bits = d->ep.relu_bits;
   k.ybytes = (uint32_t)sfk_fmap_bytes(&d->y);
+  k.ybig = sfk_fmap_bytes(&d->y) >= (1ll << 32) - 64 ? 1 : 0;
   k.ep_rbytes = d->ep.res.ptr ? (uint32_t)sfk_fmap_bytes(&d->ep.res) : 0u;
   k.bn_ybytes = (k.bn_parts && d->bnb.y_bn.ptr) ? (uint32_t)sfk_fmap_bytes(&d->bnb.y_bn) : 0u;
   k.bn_mbytes = (k.bn_parts && d->bnb.mask_src.ptr) ? (uint32_t)sfk_fmap_bytes(&d->bnb.mask_src) : 0u;

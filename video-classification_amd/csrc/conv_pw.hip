@@ -251,10 +251,10 @@ inline int pw_blocks(int M, int CG, int NT) {
   const int WPB = NT / 64;
   const int ntiles = (M + 15) / 16;
   int blocks = 256 * (NT == 512 ? 1 : 2);
-  const int need = (ntiles * CG + WPB - 1) / WPB;
-  if (blocks > need) blocks = need;
-  while ((blocks * WPB) % CG) ++blocks;
-  return blocks;
+  while ((blocks * WPB) % CG) --blocks;            // (CG = 5: 255 workgroups, not a second generation of four)
+  int need = (ntiles * CG + WPB - 1) / WPB;
+  while ((need * WPB) % CG) ++need;
+  return blocks < need ? blocks : need;
 }
 
 template <int NF, int KS, int CG, int NT, bool XDB, int MODE = 0>
@@ -310,6 +310,8 @@ int sfk_conv_pw_fused(const sfk_conv_desc* d, hipStream_t s) {
   // 134 KB of filter: one 8-wave workgroup per CU; 64 channels per wave (8 fragments at KS = 4 spill), the eight co groups
   // of a workgroup read the same X rows (L1)
   if (C == 512 && KS == 4) return pw_launch<4, 4, 8, 512, true>(k, s);
+  // 320 = 5 co groups of 64 channels (84 KB of filter: one 8-wave workgroup per CU)
+  if (C == 320 && KS == 4 && !k.res) return pw_launch<4, 4, 5, 512, true>(k, s);
   return SFK_ERR_UNSUPPORTED;
 }
 

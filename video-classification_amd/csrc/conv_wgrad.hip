@@ -298,7 +298,10 @@ __device__ __forceinline__ void wg_swap16f(float& a, float& b) {
 // TCI = 256 (256 x 256: 8 waves as 4 x 2 of 64 co x 128 columns, ONE workgroup per CU) for the MFMA-bound layers: twice the columns per staged dY row -- 32 B of LDS-DMA per MFMA cycle and CU instead of
 // 48 -- and 32 MFMAs per wave between two barriers instead of 16.  Its pixel splits ALWAYS go through the partial-tile
 // workspace (a 256 x 256 fp32 tile per split through the ~1.3 TB/s atomic path would cost more than the tile's MFMAs).
-template <int TCO, int NW, bool DG = false, int TCI = 128>
+// NS: ring slots (NS - 1 stages of LDS-DMA in flight beside the one being multiplied).  A workgroup has (NS - 1) x BUF bytes
+// on the wire; with one or two workgroups per CU that -- not the MFMAs -- sets the rate of the HBM-bound layers: by Little's
+// law 192 workgroups x 32 KB at ~2 us are 3 TB/s, which is what the 3-slot ring measured on slow res2 / res3 (3.0 .. 3.9).
+template <int TCO, int NW, bool DG = false, int TCI = 128, int NS = 3>
 __global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void conv_wgrad_dma_kernel(const WgradK k) {
   constexpr int R = MK;
   constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
@@ -309,7 +312,8 @@ __global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void
   constexpr int WCI = NW / WCO;                             // waves along the columns
   constexpr int FI = TCI / WCI / 16;                        // 16-column fragments per wave (4 or 8)
   static_assert(NW == WCO * WCI && (FI == 4 || FI == 8) && NDO >= 1 && NDI >= 1 && (!DG || TCI == 128), "tile shape");
-  __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
+  static_assert(NS >= 3 && NS <= 6 && (NS - 2) * (NDO + NDI) <= 63 && (!DG || NS == 3), "ring depth");
+  __shared__ __attribute__((aligned(16))) char smem[NS * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -399,12 +403,8 @@ __global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void
   // lgkmcnt(0): every fragment read of this stage has EXECUTED before the barrier lets other waves DMA into its slot
   // (see conv_igemm.hip ring_wait)
   auto ring_wait = [&]() {
-    static_assert(NDO + NDI >= 2 && NDO + NDI <= 6, "DMA count");
-    if constexpr (NDO + NDI == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if constexpr (NDO + NDI == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else if constexpr (NDO + NDI == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if constexpr (NDO + NDI == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    // retire the OLDEST stage in flight: the NS - 2 younger ones stay on the wire across the barrier
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * (NDO + NDI)) : "memory");
     __builtin_amdgcn_s_barrier();
   };
 
@@ -524,16 +524,19 @@ __global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void
         for (int j = 0; j < 4; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], c[j], acc[i][4 + j], 0, 0, 0);
     }
   };
-  dma(stage0, 0);
-  dma(stage0 + 1, 1);
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) dma(stage0 + i, i);
   ring_wait();
   for (int st = stage0;;) {
-    dma(st + 2, 2); compute(0 * BUF); ring_wait();
-    if (++st >= stage1) break;
-    dma(st + 2, 0); compute(1 * BUF); ring_wait();
-    if (++st >= stage1) break;
-    dma(st + 2, 1); compute(2 * BUF); ring_wait();
-    if (++st >= stage1) break;
+    bool done = false;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {              // unrolled: slot addresses are immediates
+      if (!done) {
+        dma(st + NS - 1, (sl + NS - 1) % NS); compute(sl * BUF); ring_wait();
+        done = ++st >= stage1;
+      }
+    }
+    if (done) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -621,7 +624,7 @@ int launch_reduce(const WgradK& k, int splits, hipStream_t s) {
   return SFK_OK;
 }
 
-template <int TCO, int NW, bool DG = false, int TCI = 128>
+template <int TCO, int NW, bool DG = false, int TCI = 128, int NS = 3>
 int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
   const int cotiles = (d->cout + TCO - 1) / TCO;
@@ -645,7 +648,7 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   if (dry) { *dry = need; return SFK_OK; }
   if (k.ws && need > d->workspace_bytes) k.ws = nullptr;
   if (TCI == 256 && !k.ws) return SFK_ERR_UNSUPPORTED;      // (the caller routes to the 128-column tile instead)
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG, TCI>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG, TCI, NS>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<NW, TCO / 64, 4, FI>(k, splits, s);
   return SFK_OK;
@@ -752,8 +755,9 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   }
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
-    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return launch_dma<256, 8>(k, d, s, dry);
-    return launch_dma<128, 4>(k, d, s, dry);
+    const bool deep = (sfk_tune().wgrad_wide_co & 8) != 0;       // EXPERIMENT: 5-slot ring
+    if (d->cout >= 256 && (int64_t)k.M * cols >= (1ll << 24)) return deep ? launch_dma<256, 8, false, 128, 5>(k, d, s, dry) : launch_dma<256, 8>(k, d, s, dry);
+    return deep ? launch_dma<128, 4, false, 128, 5>(k, d, s, dry) : launch_dma<128, 4>(k, d, s, dry);
   }
   if constexpr (sizeof(T) == 2) {
     // wide output, narrow input (slow res2 conv_c: 64 -> 256): ONE tile holds all of dW, so x and dY are each read once
