@@ -120,6 +120,8 @@ def instrumented_step(step, pl, frames, labels, idx, schedule="lanes", only=None
         ops["adam"](st)
 
     torch.cuda.synchronize()
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
     if lanes and step._trunk is not None:
         cur = torch.cuda.current_stream()
         step._trunk.wait_stream(cur)
@@ -131,7 +133,7 @@ def instrumented_step(step, pl, frames, labels, idx, schedule="lanes", only=None
     torch.cuda.synchronize()
     out = {}
     if per_layer and only is None:          # (the dominant-class-only pass must not overwrite the full dump)
-        rows = [dict(meta, ms=a.elapsed_time(b)) for meta, a, b in ev]
+        rows = [dict(meta, ms=a.elapsed_time(b), t_ms=base.elapsed_time(a)) for meta, a, b in ev]   # t_ms: start since the step began
         path = os.environ["SFK_PER_LAYER"] + ("" if schedule == "serial" else ".lanes")
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         with open(path, "w") as f:

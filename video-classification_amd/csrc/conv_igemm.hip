@@ -173,25 +173,38 @@ __device__ __forceinline__ float row16_sum(float v) {
 // accumulators, so its epilogue applies the ReLU mask, stores dz instead of dA, and leaves the two per-channel sums the
 // BatchNorm backward needs (sum dz, sum dz * x_hat) as per-tile partial rows, exactly as the forward pass leaves its
 // statistics.  The stand-alone reduce kernel (read dA, read y, read the mask, write dz) disappears; the epilogue reads
-// y (and the mask source) for its own tile only.  Fragment pairs are processed one at a time so that only 8 channels'
-// coefficients are live.   `red` = WM x BN x 2 floats of LDS (aliases the ring; the caller has drained it).
-// All global loads are BRANCH-FREE buffer loads (rows past M re-read row M - 1, absent operands are zero-sized resources
-// that read zeros) and the loads of two pixel rows -- y_bn, the mask source or bitmap byte, the old value of a += pass --
-// are issued before the first use: with `if (m < M) { ... load ... }` hipcc drains vmcnt behind every load, up to twelve
-// serial round trips per lane and tile, which made this epilogue cost more than the reduce kernel it replaces.
-template <int FM, int FN, int BM, int BN, int WM, int WN>
+// y (and the mask source) for its own tile only.
+// What makes or breaks it is memory-level parallelism.  A lane owns FM x FN/2 sixteen-byte groups of the tile; every global
+// load is a BRANCH-FREE buffer load (rows past M re-read row M - 1, absent operands are zero-sized resources that read
+// zeros: with `if (m < M) load` hipcc drains vmcnt behind every load) and ALL of a lane's loads -- y_bn, the old values of a
+// += pass (ACC), the mask source (MSRC) -- are issued before the first use (with three operands: one fragment pair at a
+// time, 48 VGPRs); the per-channel coefficients go through LDS once per tile (x_hat = y * ca + cb, mask = y * cs + ch > 0)
+// instead of 32 registers per fragment pair.  The first version kept two pixel rows in flight, i.e. FM / 2 x FN / 2 serial
+// round trips plus FN / 2 for the coefficients per tile: +24 .. +78 us on layers whose reduce kernel takes 17 .. 45.
+// `red` = (WM x BN x 2 + 4 x BN) floats of LDS (aliases the ring; the caller has drained it).
+template <int FM, int FN, int BM, int BN, int WM, int WN, bool ACC, bool MSRC>
 __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&acc)[FN][FM], float* red, int mt, int nt,
                                                 int wm, int wn, int lane, int tid) {
   const int l15 = lane & 15, g = lane >> 4;
   bf16_t* __restrict__ yp = static_cast<bf16_t*>(k.y);
-  constexpr bool bitmode = false;             // (bn_y == NULL, the bitmap flavour, is epilogue_bits_sum: EPI == 5)
-  const bool has_msrc = k.bn_mask != nullptr;
-  const bool relu_y = k.bn_relu && !has_msrc && !bitmode;       // mask from y * scale + shift > 0
+  const bool relu_y = k.bn_relu && !MSRC;                       // mask from y * scale + shift > 0
   const int co_w = nt * BN + wn * (BN / WN);
-  const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, k.accumulate ? k.ybytes : 0u);
-  const __amdgpu_buffer_rsrc_t r_y = sfk_make_rsrc(k.bn_y, bitmode ? 0u : k.bn_ybytes);
-  const __amdgpu_buffer_rsrc_t r_m = sfk_make_rsrc(k.bn_mask, has_msrc ? k.bn_mbytes : 0u);
-  const __amdgpu_buffer_rsrc_t r_b = sfk_make_rsrc(k.obits, bitmode ? k.obits_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t r_old = sfk_make_rsrc(k.y, (ACC || MSRC) && k.accumulate ? k.ybytes : 0u);
+  const __amdgpu_buffer_rsrc_t r_y = sfk_make_rsrc(k.bn_y, k.bn_ybytes);
+  const __amdgpu_buffer_rsrc_t r_m = sfk_make_rsrc(k.bn_mask, MSRC ? k.bn_mbytes : 0u);
+  // ---- coefficients of this tile's BN channels -> LDS (one thread per channel)
+  float* coef = red + WM * BN * 2;                              // [4][BN]: ca | cb | cs | ch
+  if (tid < BN) {
+    const int co = nt * BN + tid;
+    const int cc = co < k.cout ? co : 0;
+    const float is = k.bn_invstd[cc], mu = k.bn_mean[cc];
+    float cs = 0.f, ch = 1.f;                                   // no mask from y: y * 0 + 1 > 0
+    if (relu_y) { cs = k.bn_scale[cc]; ch = k.bn_shift[cc]; }
+    coef[tid] = is;
+    coef[BN + tid] = -mu * is;
+    coef[2 * BN + tid] = cs;
+    coef[3 * BN + tid] = ch;
+  }
   // the pixel a row maps to (clamped to the last row: nothing is stored for rows past M, their sums are masked out)
   int64_t plin[FM];
   bool rok[FM];
@@ -211,55 +224,51 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
       plin[j] = (((int64_t)n_ * k.yt + to) * k.yh + ho) * k.yw + wo;
     }
   }
+  constexpr int PG = ((MSRC || ACC) ? 1 : FN / 2);       // fragment pairs whose loads are in flight together (VGPR budget: 168)
+  bool synced = false;
 #pragma unroll
-  for (int p = 0; p < FN; p += 2) {
-    const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);       // this lane's 8 channels after the swap
-    const bool cok = co < k.cout;
-    const int cc = cok ? co : 0;
-    // per-channel coefficients: 16-byte buffer loads (zero-sized resource = zeros for an absent vector)
-    float ca[8], cb[8], cs[8], ch[8];
-    {
-      const uint32_t cbo = (uint32_t)cc * 4u, nb = (uint32_t)k.cout * 4u;
-      const __amdgpu_buffer_rsrc_t r_is = sfk_make_rsrc(k.bn_invstd, bitmode ? 0u : nb);
-      const __amdgpu_buffer_rsrc_t r_mu = sfk_make_rsrc(k.bn_mean, bitmode ? 0u : nb);
-      const __amdgpu_buffer_rsrc_t r_sc = sfk_make_rsrc(k.bn_scale, relu_y ? nb : 0u);
-      const __amdgpu_buffer_rsrc_t r_sh = sfk_make_rsrc(k.bn_shift, relu_y ? nb : 0u);
-      const uint4 i0 = sfk_buffer_load16(r_is, cbo), i1 = sfk_buffer_load16(r_is, cbo + 16);
-      const uint4 m0 = sfk_buffer_load16(r_mu, cbo), m1 = sfk_buffer_load16(r_mu, cbo + 16);
-      const uint4 s0 = sfk_buffer_load16(r_sc, cbo), s1_ = sfk_buffer_load16(r_sc, cbo + 16);
-      const uint4 h0 = sfk_buffer_load16(r_sh, cbo), h1 = sfk_buffer_load16(r_sh, cbo + 16);
-      const uint32_t iv[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-      const uint32_t mv_[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-      const uint32_t sv[8] = {s0.x, s0.y, s0.z, s0.w, s1_.x, s1_.y, s1_.z, s1_.w};
-      const uint32_t hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  for (int p0 = 0; p0 < FN; p0 += 2 * PG) {
+    bf16x8 yv[PG][FM], oldv[(ACC || MSRC) ? PG : 1][(ACC || MSRC) ? FM : 1], mv[MSRC ? PG : 1][MSRC ? FM : 1];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float is = __uint_as_float(iv[e]);                     // (bitmode: 0)
-        ca[e] = is;
-        cb[e] = -__uint_as_float(mv_[e]) * is;                        // x_hat = y * ca + cb
-        cs[e] = relu_y ? __uint_as_float(sv[e]) : 0.f;
-        ch[e] = relu_y ? __uint_as_float(hv[e]) : 1.f;                // no mask from y: y * 0 + 1 > 0
+    for (int q = 0; q < PG; ++q) {
+      const int p = p0 + 2 * q;
+      const int co = co_w + 16 * (p + (g & 1)) + 8 * (g >> 1);
+      const int cc = co < k.cout ? co : 0;
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        yv[q][j] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_y, (uint32_t)((plin[j] * k.bn_yld + k.bn_yoff + cc) * 2)));
+        if constexpr (ACC || MSRC)
+          oldv[q][j] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_old, (uint32_t)((plin[j] * k.yld + k.yoff + cc) * 2)));
+        if constexpr (MSRC)
+          mv[q][j] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_m, (uint32_t)((plin[j] * k.bn_mld + k.bn_moff + cc) * 2)));
       }
     }
-    float s1[8], s2[8];
+    if (!synced) {             // the coefficients are in LDS (and every wave is past the K loop's last fragment reads)
+      __syncthreads();
+      synced = true;
+    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    constexpr int JB = FM >= 2 ? 2 : 1;       // pixel rows whose loads are in flight together (register budget of the 128-VGPR tiles)
+    for (int q = 0; q < PG; ++q) {
+      const int p = p0 + 2 * q;
+      const int col0 = wn * (BN / WN) + 16 * (p + (g & 1)) + 8 * (g >> 1);     // this lane's 8 channels within the tile
+      const int co = nt * BN + col0;
+      const bool cok = co < k.cout;
+      float ca[8], cb[8], cs[8], ch[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(coef + col0), a1 = *reinterpret_cast<const float4*>(coef + col0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(coef + BN + col0), b1 = *reinterpret_cast<const float4*>(coef + BN + col0 + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(coef + 2 * BN + col0), c1 = *reinterpret_cast<const float4*>(coef + 2 * BN + col0 + 4);
+        const float4 d0 = *reinterpret_cast<const float4*>(coef + 3 * BN + col0), d1 = *reinterpret_cast<const float4*>(coef + 3 * BN + col0 + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-    for (int j0 = 0; j0 < FM; j0 += JB) {
-      bf16x8 oldv[JB], yv[JB], mv[JB];
-      uint32_t mbyte[JB];
-#pragma unroll
-      for (int jj = 0; jj < JB; ++jj) {
-        const int j = j0 + jj;
-        oldv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_old, (uint32_t)((plin[j] * k.yld + k.yoff + cc) * 2)));
-        yv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_y, (uint32_t)((plin[j] * k.bn_yld + k.bn_yoff + cc) * 2)));
-        mv[jj] = __builtin_bit_cast(bf16x8, sfk_buffer_load16(r_m, (uint32_t)((plin[j] * k.bn_mld + k.bn_moff + cc) * 2)));
-        mbyte[jj] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r_b, (int)(plin[j] * (k.cout >> 3) + (cc >> 3)), 0, 0);
+        for (int e = 0; e < 8; ++e) { ca[e] = av[e]; cb[e] = bv[e]; cs[e] = cv[e]; ch[e] = dv[e]; }
       }
+      float s1[8], s2[8];
 #pragma unroll
-      for (int jj = 0; jj < JB; ++jj) {
-        const int j = j0 + jj;
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
         float v[8] = {acc[p][j][0], acc[p][j][1], acc[p][j][2], acc[p][j][3],
                       acc[p + 1][j][0], acc[p + 1][j][1], acc[p + 1][j][2], acc[p + 1][j][3]};
 #pragma unroll
@@ -268,9 +277,12 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float vv = v[e] + (float)oldv[jj][e];                 // (no accumulate: zero-sized resource, + 0)
-          const float yf = (float)yv[jj][e];
-          const bool keep = bitmode ? ((mbyte[jj] >> e) & 1u) : (has_msrc ? ((float)mv[jj][e] > 0.f) : (yf * cs[e] + ch[e] > 0.f));
+          float vv = v[e];
+          if constexpr (ACC || MSRC) vv += (float)oldv[q][j][e];       // (no accumulate: zero-sized resource, + 0)
+          const float yf = (float)yv[q][j][e];
+          bool keep;
+          if constexpr (MSRC) keep = (float)mv[q][j][e] > 0.f;
+          else keep = yf * cs[e] + ch[e] > 0.f;
           // dz is what the BatchNorm backward sees: the value as it is STORED (bf16), masked
           const bf16_t dzb = (bf16_t)(keep ? vv : 0.f);
           const float dz = live ? (float)dzb : 0.f;
@@ -280,14 +292,13 @@ __device__ __forceinline__ void epilogue_bn_bwd(const ConvK& k, const f32x4 (&ac
         }
         if (live) *reinterpret_cast<bf16x8*>(yp + plin[j] * k.yld + k.yoff + co) = o;
       }
-    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
-      if (l15 == 15) {
-        const int col = wn * (BN / WN) + 16 * (p + (g & 1)) + 8 * (g >> 1) + e;
-        red[(wm * BN + col) * 2 + 0] = a;
-        red[(wm * BN + col) * 2 + 1] = b;
+      for (int e = 0; e < 8; ++e) {
+        const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
+        if (l15 == 15) {
+          red[(wm * BN + col0 + e) * 2 + 0] = a;
+          red[(wm * BN + col0 + e) * 2 + 1] = b;
+        }
       }
     }
   }
@@ -768,7 +779,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvK& k, const f32x4 (&acc
   }
 }
 
-// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb; 5 = its bitmap flavour), 2 output ReLU bitmap (out_relu_bits), 3 fused output
+// EPI: 0 plain epilogue, 1 fused BatchNorm-backward reduce (bnb; 5 = its bitmap flavour, 6 = += pass, 7 = mask source), 2 output ReLU bitmap (out_relu_bits), 3 fused output
 // transform (sfk_conv_epilogue) -- own
 // instantiations: the extra epilogue state must not cost the plain kernel registers (the 256x128 tile sits at 128 VGPRs)
 template <typename T, int BM, int BN, int WM, int WN, bool SHORTK, int EPI = 0>
@@ -956,10 +967,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void conv_igemm_kern
   }
 
   // ---- epilogue: channels-last stores (4 consecutive co per lane per fragment)
-  if constexpr ((EPI == 1 || EPI == 5) && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: own instantiations
+  if constexpr ((EPI == 1 || EPI >= 5) && sizeof(T) == 2 && (FN % 2) == 0) {   // fused BatchNorm-backward reduce: own instantiations
     __syncthreads();        // the partial sums go through LDS that aliases the ring
     if constexpr (EPI == 5) epilogue_bits_sum<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
-    else epilogue_bn_bwd<FM, FN, BM, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    else epilogue_bn_bwd<FM, FN, BM, BN, WM, WN, EPI == 6, EPI == 7>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
   if constexpr (EPI == 3) {
@@ -1182,9 +1193,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BN == 256 ? 2 : (WM * WN == 8 ? 4 : 
   __syncthreads();
 
   // ---- epilogue
-  if constexpr (EPI == 1 || EPI == 5) {      // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
+  if constexpr (EPI == 1 || EPI == 5 || EPI == 6 || EPI == 7) {   // fused BatchNorm-backward reduce; the ring is drained (vmcnt(0) + barrier above)
     if constexpr (EPI == 5) epilogue_bits_sum<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
-    else epilogue_bn_bwd<FM, FN, BMS, BN, WM, WN>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
+    else epilogue_bn_bwd<FM, FN, BMS, BN, WM, WN, EPI == 6, EPI == 7>(k, acc, reinterpret_cast<float*>(smem), mt, nt, wm, wn, lane, tid);
     return;
   }
   if constexpr (EPI == 3) {
@@ -1359,7 +1370,10 @@ int launch_dma(const ConvK& k, int bm, dim3 grid, hipStream_t s, int bn = 128) {
     return SFK_OK;
   }
   if (k.bn_parts) {          // (pick_tile: never 256 x 128); 5 = the bitmap flavour (mask = out_relu_bits, sums of dz only)
+    // (6 = with the old values of a += pass, 7 = with a mask source)
     if (k.bn_y == nullptr) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 5>), grid, dim3(256), 0, s, k);
+    else if (k.bn_mask) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 7>), grid, dim3(256), 0, s, k);
+    else if (k.accumulate) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 6>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
@@ -1452,6 +1466,14 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
         if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 5>), grid, block, 0, s, k);
         else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 5>), grid, block, 0, s, k);
         else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 5>), grid, block, 0, s, k);
+      } else if (k.bn_mask) {       // with a mask source
+        if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 7>), grid, block, 0, s, k);
+        else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 7>), grid, block, 0, s, k);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 7>), grid, block, 0, s, k);
+      } else if (k.accumulate) {    // with the old values of a += pass
+        if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 6>), grid, block, 0, s, k);
+        else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 6>), grid, block, 0, s, k);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 6>), grid, block, 0, s, k);
       } else if (ts.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2, false, 1>), grid, block, 0, s, k);
       else if (ts.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 64, 4, 1, false, 1>), grid, block, 0, s, k);
       else hipLaunchKernelGGL((conv_igemm_kernel<T, 256, 32, 4, 1, false, 1>), grid, block, 0, s, k);
