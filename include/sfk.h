@@ -38,8 +38,8 @@ extern "C" {
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256; 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
- * of `a` from it (no constant-1 channel group beside the activation any more). */
-#define SFK_ABI_VERSION 12
+ * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual. */
+#define SFK_ABI_VERSION 13
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -326,6 +326,18 @@ int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, co
 /* r [cout][c]; dz_partials [nparts][cout][2], component 0 = partial sums of dz as the kernel that WROTE dz left them
  * (sfk_bn_bwd_reduce with y == NULL, or the data-gradient pass with bnb.y_bn.ptr == NULL + out_relu_bits); coef: [cout][4]
  * fp32 scratch */
+
+/* Both data-gradient passes of that tail in ONE pass over the pixels, for the narrow maps of the fast pathway (bf16):
+ *     y[pix][co] = sum_k x1[pix][k] w1[co][k] + sum_k x2[pix][k] w2[co][k] + bias[co]
+ * i.e. da = dz (A W)^T + a m + bias with x1 = dz, w1 = wd of sfk_bn_tail_fwd, x2 = a, w2 = m and bias of sfk_bn_tail_bwd:
+ * da is written once instead of written, re-read and re-written (96 instead of 128 bytes per pixel on fast res2, and one
+ * streaming pass instead of two MFMA tiles that are all epilogue at 8 .. 16 output channels).  fp32 accumulation, one
+ * rounding; all three maps share the pixel grid, w1 [y.c][x1.c], w2 [y.c][x2.c] row-major in the maps' dtype, bias fp32 or NULL.
+ * sfk_conv_pw_dual_supported: 1 for the channel counts the kernel is built for ((x1.c, x2.c, y.c) = (32, 8, 8), (64, 16, 16)),
+ * bf16, 16-byte aligned pixel records; everything else keeps the two sfk_conv_igemm passes. */
+int sfk_conv_pw_dual_supported(const sfk_fmap* x1, const sfk_fmap* x2, const sfk_fmap* y);
+int sfk_conv_pw_dual(const sfk_fmap* x1, const void* w1, const sfk_fmap* x2, const void* w2, const float* bias,
+                     const sfk_fmap* y, sfk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MaxPool3d (1,k,k)/(1,s,s)/(0,p,p) of the stems (my_slowfast.py:66-68).  `argmax` (uint8 per output

@@ -190,6 +190,21 @@ class EmuBackend:
             bias[:c].copy_((Cc @ W).float())
         return run
 
+    @staticmethod
+    def conv_pw_dual_supported(x1, x2, y) -> bool:
+        return y.buf.dtype == torch.bfloat16 and (x1.c, x2.c, y.c) in ((32, 8, 8), (64, 16, 16))
+
+    def conv_pw_dual(self, x1, w1, x2, w2, bias, y):
+        """y = x1 w1^T + x2 w2^T + bias (include/sfk.h sfk_conv_pw_dual): fp32 accumulation, one rounding"""
+        def run(stream):
+            W1 = w1[: y.c * x1.c].view(y.c, x1.c).float()
+            W2 = w2[: y.c * x2.c].view(y.c, x2.c).float()
+            out = x1.view5().float() @ W1.t() + x2.view5().float() @ W2.t()
+            if bias is not None:
+                out = out + bias[: y.c].float()
+            y.view5().copy_(out.to(y.buf.dtype))
+        return run
+
     def conv_wgrad(self, p: WgradPass):
         def run(stream):
             X = p.x.view5().float()

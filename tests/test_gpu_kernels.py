@@ -890,6 +890,35 @@ def test_conv_pointwise_streaming_plain_bf16(hip, shape):
             assert rel_err(sg_.sum(0), sc_.sum(0)) < 1e-4 and float(tailg.min()) == 5.0 == float(tailg.max())
 
 
+@pytest.mark.parametrize("shape", [(32, 8, 8), (64, 16, 16)], ids=str)
+def test_conv_pw_dual_bf16(hip, shape):
+    """sfk_conv_pw_dual: both data-gradient passes of a narrow block tail in one streaming kernel, against the restated
+    contract (fp32 accumulation, one rounding: 1 bf16 ulp), channel slices of wider pixel records, ragged pixel count"""
+    c1, c2, co = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    emu = EmuBackend()
+    dtype = torch.bfloat16
+    n, t, h, w = 3, 3, 11, 13                                     # 1287 pixels: not a multiple of the 256-thread blocks
+    x1c, x1g = fmap_pair(n, c1, t, h, w, dtype, gen, ld=c1 + 8, c_off=8)
+    x2c, x2g = fmap_pair(n, c2, t, h, w, dtype, gen)
+    w1 = mk((co * c1,), dtype, gen, scale=c1 ** -0.5)
+    w2 = mk((co * c2,), dtype, gen, scale=c2 ** -0.5)
+    bias = torch.randn(co, generator=gen)
+    for use_bias in (True, False):
+        yc, yg = fmap_pair(n, co, t, h, w, dtype, gen, ld=co + 8, c_off=8)
+        assert hip.conv_pw_dual_supported(x1g, x2g, yg) and emu.conv_pw_dual_supported(x1c, x2c, yc)
+        emu.conv_pw_dual(x1c, w1, x2c, w2, bias if use_bias else None, yc)(0)
+        hip.conv_pw_dual(x1g, w1.to(DEV), x2g, w2.to(DEV), bias.to(DEV) if use_bias else None, yg)(stream())
+        torch.cuda.synchronize()
+        got, want = yg.buf.float().cpu(), yc.buf.float()
+        assert rel_err(got, want) < TOL[dtype]
+        assert torch.equal(got.view(-1, co + 8)[:, :8], want.view(-1, co + 8)[:, :8])          # the neighbouring slice is untouched
+    # other channel counts keep the two sfk_conv_igemm passes
+    ac, ag = fmap_pair(1, 128, 1, 4, 4, dtype, gen)
+    bc, bg = fmap_pair(1, 32, 1, 4, 4, dtype, gen)
+    assert not hip.conv_pw_dual_supported(ag, bg, bg)
+
+
 def test_conv_masked_store_with_dz_sums_bf16(hip):
     """sfk_bn_bwd_fuse with y_bn = NULL + out_relu_bits: the data-gradient pass that finishes a block's output gradient
     stores dz = (old + result) * bitmap and leaves the per-tile partial sums of the STORED dz (what sfk_bn_tail_bwd folds)"""

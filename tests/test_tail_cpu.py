@@ -132,3 +132,28 @@ def test_tail_projection_shortcut_affine():
     assert rel_err(got["out"], ref["out"].float()) < 1e-5
     for k in ("dgamma", "dbeta", "dW", "da"):
         assert rel_err(got[k], ref[k].float()) < 2e-4, k
+
+
+@pytest.mark.parametrize("c,cout", [(8, 32), (16, 64)])
+def test_dual_pass_equals_the_two_data_gradient_passes(c, cout):
+    """sfk_conv_pw_dual's contract: y = x1 w1^T + x2 w2^T + bias == the plain pass followed by the += pass with a bias, up to
+    the one bf16 rounding the two-pass form does in between (tests/emu_backend.py states the contract; the GPU kernel is
+    checked against it in tests/test_gpu_kernels.py)"""
+    be = EmuBackend()
+    g = torch.Generator().manual_seed(c)
+    bf = torch.bfloat16
+    n, t, h, w = 2, 2, 5, 7
+    dz = FMap((torch.randn(n * t * h * w * cout, generator=g)).to(bf), n, t, h, w, cout)
+    a = FMap(torch.relu(torch.randn(n * t * h * w * c, generator=g)).to(bf), n, t, h, w, c)
+    wd = (torch.randn(c * cout, generator=g) * cout ** -0.5).to(bf)
+    m = (torch.randn(c * c, generator=g) * c ** -0.5).to(bf)
+    bias = torch.randn(c, generator=g)
+    assert be.conv_pw_dual_supported(dz, a, FMap(torch.zeros(n * t * h * w * c, dtype=bf), n, t, h, w, c))
+    y1 = FMap(torch.zeros(n * t * h * w * c, dtype=bf), n, t, h, w, c)
+    be.conv_pw_dual(dz, wd, a, m, bias, y1)(0)
+    y2 = FMap(torch.zeros(n * t * h * w * c, dtype=bf), n, t, h, w, c)
+    be.conv_igemm(ConvPass(dz, y2, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, wd, 1, cout, c))(0)
+    be.conv_igemm(ConvPass(a, y2, (t, h, w), ONE, ONE, (0, 0, 0), TAP0, m, 1, c, c, accumulate=True, ep=ConvEpilogue(shift=bias)))(0)
+    assert rel_err(y1.buf.float(), y2.buf.float()) < 1e-2          # (bf16: the two-pass form rounds the first pass's result)
+    ref = dz.view5().double() @ wd.view(c, cout).double().t() + a.view5().double() @ m.view(c, c).double().t() + bias.double()
+    assert rel_err(y1.view5().float(), ref.float()) < 4e-3

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 12       # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 13       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -221,6 +221,8 @@ SIGNATURES = {
     "sfk_conv_igemm_family": [C.POINTER(_ConvDesc)],
     "sfk_bn_tail_fwd": [_PF, _PF, _I32, _I64, _PF, _I32, _PV, _I32, _I32, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PF, _PF, _PV, _PV],
     "sfk_bn_tail_bwd": [_PF, _PF, _I32, _PF, _I64, _PF, _I32, _PV, _I32, _I32, _PF, _PF, _PF, _PF, _PF, _PF, _PV, _PF, _PF, _PV],
+    "sfk_conv_pw_dual_supported": [_P_FMAP, _P_FMAP, _P_FMAP],
+    "sfk_conv_pw_dual": [_P_FMAP, _PV, _P_FMAP, _PV, _PF, _P_FMAP, _PV],
     "sfk_conv_wgrad": [C.POINTER(_WgradDesc), _PV],
     "sfk_conv_wgrad_workspace_bytes": [C.POINTER(_WgradDesc)],
     "sfk_conv_wgrad_dg_supported": [C.POINTER(_WgradDesc)],
@@ -609,6 +611,16 @@ class HipBackend:
         return self._plain("sfk_bn_tail_bwd", _ptr(r), _ptr(dz_partials), nparts, _ptr(g), count, _ptr(t), c, _ptr(w),
                            _DT[w.dtype], cout, _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
                            _ptr(m), _ptr(bias), _ptr(coef), keep=ts)
+
+    def conv_pw_dual_supported(self, x1: FMap, x2: FMap, y: FMap) -> bool:
+        f1, f2, fy = _c_fmap(x1), _c_fmap(x2), _c_fmap(y)
+        return bool(load().sfk_conv_pw_dual_supported(C.byref(f1), C.byref(f2), C.byref(fy)))
+
+    def conv_pw_dual(self, x1: FMap, w1, x2: FMap, w2, bias, y: FMap):
+        """y = x1 w1^T + x2 w2^T + bias in one pass (both data-gradient passes of a narrow block tail: include/sfk.h)"""
+        f1, f2, fy = _c_fmap(x1), _c_fmap(x2), _c_fmap(y)
+        return self._plain("sfk_conv_pw_dual", C.byref(f1), _ptr(w1), C.byref(f2), _ptr(w2), _ptr(bias), C.byref(fy),
+                           keep=(f1, f2, fy, x1, x2, y, w1, w2, bias))
 
     # -- pooling / head / loss
     def maxpool_fwd(self, x: FMap, y: FMap, argmax, k, s, p):

@@ -272,6 +272,86 @@ int pw_launch(const PwK& k, hipStream_t s) {
   return SFK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-source pointwise pass for the narrowest maps (sfk_conv_pw_dual): y = x1 w1^T + x2 w2^T + bias with 8 or 16 output
+// channels.  An MFMA tile of 16 output channels is all epilogue here (and half empty at 8); this is a plain streaming
+// kernel: a thread owns a pixel -- its x1 / x2 rows are 16-byte loads, its output row ONE 16 / 32-byte store --, the two
+// filters sit in LDS as packed bf16 pairs (every lane reads the same address: a broadcast), products through
+// v_dot2c_f32_bf16 (two bf16 x bf16 products, exact in fp32, into an fp32 accumulator).  U pixels per thread are in flight.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+template <int C1, int C2, int CO>
+__global__ __launch_bounds__(256, 4) void pw_dual_kernel(const bf16_t* __restrict__ x1, int ld1, int off1,
+                                                      const bf16_t* __restrict__ x2, int ld2, int off2,
+                                                      const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                                      const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int offy,
+                                                      int64_t pixels) {
+  constexpr int KP = (C1 + C2) / 2;                     // bf16 pairs per output channel
+  __shared__ __attribute__((aligned(16))) uint32_t wl[CO * KP];   // [co][pair]: w1 row then w2 row
+  __shared__ float bl[CO];
+  for (int i = threadIdx.x; i < CO * KP; i += 256) {
+    const int co = i / KP, kp = i % KP;
+    const bf16_t* src = kp < C1 / 2 ? w1 + co * C1 + 2 * kp : w2 + co * C2 + 2 * (kp - C1 / 2);
+    wl[i] = *reinterpret_cast<const uint32_t*>(src);
+  }
+  if (threadIdx.x < CO) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  constexpr int U = 1;         // pixels per thread in flight (two made hipcc spill 82 registers on the 8-channel variant)
+  for (int64_t p0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x; p0 < pixels; p0 += (int64_t)gridDim.x * 256 * U) {
+    uint4 a[U][C1 / 8], b[U][C2 / 8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = p0 + u * 256 < pixels ? p0 + u * 256 : p0;      // past the end: re-read p0 (not stored)
+#pragma unroll
+      for (int i = 0; i < C1 / 8; ++i) a[u][i] = *reinterpret_cast<const uint4*>(x1 + p * ld1 + off1 + 8 * i);
+#pragma unroll
+      for (int i = 0; i < C2 / 8; ++i) b[u][i] = *reinterpret_cast<const uint4*>(x2 + p * ld2 + off2 + 8 * i);
+    }
+    // eight output channels at a time (one 16-byte store each); the laundered offset after every channel keeps the compiler
+    // from hoisting ALL filter reads above the first product (it did: 512 VGPRs + 900 B of scratch)
+    uint32_t woff = 0;           // (always 0; laundered after every channel so that the next channel's filter reads depend on it)
+    for (int c8 = 0; c8 < CO; c8 += 8) {
+      float acc[U][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = c8 + j;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u][j] = bl[co];
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) {                 // four pairs (16 bytes of filter) per LDS read
+          const uint4 wv = *reinterpret_cast<const uint4*>(&wl[co * KP + 4 * q + woff]);
+          const uint32_t wp[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint4 xv = q < C1 / 8 ? a[u][q < C1 / 8 ? q : 0] : b[u][q >= C1 / 8 ? q - C1 / 8 : 0];
+            const uint32_t xp[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[u][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xp[e]), __builtin_bit_cast(bf16x2_t, wp[e]),
+                                                          acc[u][j], false);
+          }
+        }
+        asm volatile("" : "+v"(woff) : "v"(acc[0][j]));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * 256;
+        if (p < pixels) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[u][e];
+          *reinterpret_cast<bf16x8*>(y + p * ldy + offy + c8) = o;
+        }
+      }
+    }
+  }
+}
+
+inline bool pw_dual_map_ok(const sfk_fmap* f) {
+  return sfk_fmap_ok(f) && f->dtype == SFK_BF16 && (f->c % 8) == 0 && (f->ld % 8) == 0 && (f->c_off % 8) == 0 &&
+         (((uintptr_t)f->ptr) & 15) == 0;
+}
+
 }  // namespace
 
 // Called by sfk_conv_igemm's dispatch (conv_igemm.hip) for descriptors it has validated: bf16, one tap at the pixel itself,
@@ -336,4 +416,31 @@ int sfk_conv_pw_dgrad(const sfk_conv_desc* d, hipStream_t s) {
   if (d->cin == 64 && d->cout == 256) return pw_launch<8, 2, 2, 256, true, 1>(k, s);
   if (d->cin == 128 && d->cout == 512) return pw_launch<4, 4, 8, 512, true, 1>(k, s);
   return SFK_ERR_UNSUPPORTED;
+}
+
+extern "C" int sfk_conv_pw_dual_supported(const sfk_fmap* x1, const sfk_fmap* x2, const sfk_fmap* y) {
+  if (!x1 || !x2 || !y || !pw_dual_map_ok(x1) || !pw_dual_map_ok(x2) || !pw_dual_map_ok(y)) return 0;
+  if (sfk_fmap_pixels(x1) != sfk_fmap_pixels(y) || sfk_fmap_pixels(x2) != sfk_fmap_pixels(y)) return 0;
+  return (x1->c == 32 && x2->c == 8 && y->c == 8) || (x1->c == 64 && x2->c == 16 && y->c == 16);
+}
+
+extern "C" int sfk_conv_pw_dual(const sfk_fmap* x1, const void* w1, const sfk_fmap* x2, const void* w2, const float* bias,
+                                const sfk_fmap* y, sfk_stream_t stream) {
+  if (!x1 || !x2 || !y || !w1 || !w2 || !sfk_fmap_ok(x1) || !sfk_fmap_ok(x2) || !sfk_fmap_ok(y)) return SFK_ERR_INVALID;
+  if (!sfk_conv_pw_dual_supported(x1, x2, y)) return SFK_ERR_UNSUPPORTED;
+  const int64_t px = sfk_fmap_pixels(y);
+  int64_t blocks = (px + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t *a = static_cast<const bf16_t*>(x1->ptr), *b = static_cast<const bf16_t*>(x2->ptr);
+  const bf16_t *u = static_cast<const bf16_t*>(w1), *v = static_cast<const bf16_t*>(w2);
+  bf16_t* o = static_cast<bf16_t*>(y->ptr);
+  if (y->c == 8)
+    hipLaunchKernelGGL((pw_dual_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, a, x1->ld, x1->c_off, b, x2->ld, x2->c_off,
+                       u, v, bias, o, y->ld, y->c_off, px);
+  else
+    hipLaunchKernelGGL((pw_dual_kernel<64, 16, 16>), dim3((unsigned)blocks), dim3(256), 0, s, a, x1->ld, x1->c_off, b, x2->ld, x2->c_off,
+                       u, v, bias, o, y->ld, y->c_off, px);
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
 }

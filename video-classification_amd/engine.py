@@ -141,6 +141,7 @@ class Engine:
         # BatchNorm-backward reduce folded into the dgrad epilogues (sfk_conv_desc.bnb): removes 3.3 ms of reduce kernels,
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
+        self.tail_dual = os.environ.get("SFK_TAIL_DUAL", "1") != "0"     # sfk_conv_pw_dual for the narrowest block tails
         # diagnostic: kernel classes (OpList meta kinds, comma separated) that the lane scheduler SKIPS -- what does the step time
         # owe to one class?  (tools/gpu_ablate.sh; results are garbage with anything skipped)
         self._ablate_kinds = frozenset(k for k in os.environ.get("SFK_ABLATE", "").split(",") if k)
@@ -760,7 +761,11 @@ class Engine:
         else:
             pl.bwd.append(self.be.conv_wgrad(wp), **meta)
         pl.bwd.cur_lane = home
-        if not fused_dg:
+        # the narrowest maps (fast res2 / res3: 8 / 16 channels): both passes in ONE streaming kernel after the small algebra
+        # (sfk_conv_pw_dual: da written once; two MFMA tiles that are all epilogue become one pass at HBM speed)
+        dual = (not fused_dg and rl == home and self.tail_dual and hasattr(self.be, "conv_pw_dual_supported")
+                and self.be.conv_pw_dual_supported(d_out, ab, dab))
+        if not fused_dg and not dual:
             pl.bwd.append(self.be.conv_igemm(ConvPass(d_out, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, tail["wd"], 1, C, c4)),
                           kind="conv_dgrad", layer=Lc.cb.conv_key, cout=c4, flops=2.0 * d_out.pixels * C * c4,
                           bytes=float(esz * (d_out.pixels * C + d_out.pixels * c4 + Lc.w_numel)))
@@ -774,6 +779,11 @@ class Engine:
                                           self._gslice(Lc.w_off, Lc.w_numel), m, bias, coef))
         pl.grad_marks.append((len(pl.bwd), (Lc.g_off, Lc.b_off + round_up(C, self.vec) - Lc.g_off)))
         pl.grad_marks.append((len(pl.bwd), (Lc.w_off, round_up(Lc.w_numel, self.vec))))
+        if dual:
+            pl.bwd.append(self.be.conv_pw_dual(d_out, tail["wd"], ab, m, bias, dab),
+                          kind="conv_dgrad", layer=Lc.cb.conv_key + ":dual", cout=c4, flops=2.0 * d_out.pixels * (C + c4) * c4,
+                          bytes=float(esz * d_out.pixels * (C + 2 * c4)))
+            return
         pl.bwd.append(self.be.conv_igemm(ConvPass(ab, dab, rows, (1, 1, 1), (1, 1, 1), (0, 0, 0), self.TAP0, m, 1, c4, c4,
                                                   accumulate=True, ep=ConvEpilogue(shift=bias))),
                       kind="conv_dgrad", layer=Lc.cb.conv_key + ":m", cout=c4, flops=2.0 * d_out.pixels * c4 * c4,
@@ -884,11 +894,26 @@ class Engine:
         n = x_slow.shape[0]
         # ---- refresh the compute-precision filter copies from the fp32 master arena
         #      (one launch: cast into the forward layout and, for training, the data-gradient transposes)
+        # On the four-lane training schedule the launch is split: the stems' filters on the trunk (a few KB), everything else
+        # on the idle filter-gradient lane BESIDE the stems, which are the first 0.6 ms of the step and read no other filter;
+        # the pathways wait for it before their first non-stem conv (the 110 us of the single launch sat in front of the step
+        # with nothing to overlap them)
+        refresh_lane = None
         if self.dtype != torch.float32 or train:
-            pl.fwd.append(be.filter_refresh(self.P.data, self.S if self.dtype != torch.float32 else None,
-                                            self.St if train else None,
-                                            [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad)
-                                             for L in self.layers]))
+            s_ = self.S if self.dtype != torch.float32 else None
+            ent = lambda Ls: [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad) for L in Ls]
+            stem_keys = {st.conv_key for st in W.stems}
+            split = (train and NP == 2 and self.two_streams and self.wgrad_lanes and self.device.type == "cuda"
+                     and os.environ.get("SFK_SPLIT_REFRESH", "1") != "0")
+            if split:
+                pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key in stem_keys])))
+                refresh_lane = 2
+                pl.fwd.sync(refresh_lane, 0)                  # after the previous step's optimiser (trunk order)
+                pl.fwd.cur_lane = refresh_lane
+                pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key not in stem_keys])))
+                pl.fwd.cur_lane = 0
+            else:
+                pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St if train else None, ent(self.layers)))
         if self._tailz["f"] is not None:
             pl.fwd.append(be.fill_zero(self._tailz["f"]))
         # ---- geometry after the stems
@@ -922,6 +947,9 @@ class Engine:
             F_.cur_lane = 1
             stem_recs.append(self._stem_fwd(pl, 1, x_fast, None, xf, train))
         fusion_recs = [None] * 4
+        if refresh_lane is not None:                    # the non-stem filter copies are ready (split refresh, above)
+            F_.sync(1, refresh_lane)
+            F_.sync(0, refresh_lane)
         if fuse:
             fusion_recs[0] = self._fusion_fwd(pl, 0, xf, cat0.channels(c_s, cat0.c - c_s), train)
             F_.sync(0, 1)                               # the slow pathway reads the fused channels
