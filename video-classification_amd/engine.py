@@ -104,6 +104,8 @@ class Plan:
         # (index one past the backward op that finishes it, (arena offset, numel)): every gradient range has ONE writer
         self.grad_marks: List[Tuple[int, Tuple[int, int]]] = []
         self.stem_state: Dict[int, dict] = {}             # per pathway: buffers + slots of the ops bound to the clip tensors
+        self.tail_cut: Optional[Tuple[int, int]] = None   # (index of the fast stem's filter-gradient op in bwd, arena offset
+                                                          #  below which only stem filters live): see Engine.adam_split_ops
 
     def grad_segments(self, nseg: int) -> List[Tuple[int, int, List[Tuple[int, int]]]]:
         """Cut the backward schedule into nseg pieces [(op_begin, op_end, finished gradient ranges)], balanced by
@@ -559,6 +561,12 @@ class Engine:
             bwd = self.be.stem_conv_wgrad(src, st["da"], self._gslice(L.w_off, L.w_numel))
             if st["bwd_slot"] is None:
                 st["bwd_slot"] = len(pl.bwd)
+                if p == 1:
+                    # the fast stem's filter gradient is the LAST kernel of the step (the trunk has finished ~0.4 ms before it):
+                    # TrainStep updates everything above `cut` beside it and only the stems' filters after it (adam_split_ops)
+                    cut = L.w_off + round_up(L.w_numel, self.vec)
+                    if all(M.w_off >= cut or M.cb.is_stem for M in self.layers):
+                        pl.tail_cut = (len(pl.bwd), cut)
                 pl.bwd.append(bwd, kind="stem_wgrad", layer=L.cb.conv_key, cout=L.c, flops=flops, bytes=meta["bytes"])
                 pl.grad_marks.append((len(pl.bwd), (L.w_off, round_up(L.w_numel, self.vec))))
             else:
@@ -1181,10 +1189,26 @@ class Engine:
         n, k = pl.logits.shape
         return self.be.softmax_ce(pl.logits, labels, n, k, gscale, pl.dlogits, loss_out, loss_sum, correct)
 
-    def adam_ops(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> Run:
+    def _adam_state(self):
         if self.adam_m is None:
             self.adam_m = self._new(self.arena_numel)
             self.adam_v = self._new(self.arena_numel)
             self.adam_step = self._new(1, dtype=torch.int64)
+
+    def adam_ops(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> Run:
+        self._adam_state()
         return self.be.adam(self.P.data, self.G, self.adam_m, self.adam_v, self.arena_numel, lr, betas[0], betas[1],
                             eps, grad_scale, self.adam_step, None)
+
+    def adam_split_ops(self, cut: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        """(main, tail): the same update as adam_ops in two launches -- arena [cut:] (increments the step counter) and [:cut]
+        (the stems' filters; sfk_adam increments the counter it is given, so the tail gets a scratch counter that
+        TrainStep sets to step - 1 first).  Element-wise identical to the single launch."""
+        self._adam_state()
+        n = self.arena_numel
+        self.adam_step_tail = self._new(1, dtype=torch.int64)
+        main = self.be.adam(self.P.data[cut:], self.G[cut:], self.adam_m[cut:], self.adam_v[cut:], n - cut, lr, betas[0],
+                            betas[1], eps, grad_scale, self.adam_step, None)
+        tail = self.be.adam(self.P.data[:cut], self.G[:cut], self.adam_m[:cut], self.adam_v[:cut], cut, lr, betas[0],
+                            betas[1], eps, grad_scale, self.adam_step_tail, None)
+        return main, tail

@@ -76,6 +76,10 @@ class TrainStep:
             zero_loss=eng.be.fill_zero(self.loss),
             zero_grad=eng.be.fill_zero(eng.G),
         )
+        # the optimiser beside the last kernel of the step (engine.Plan.tail_cut): eager four-lane single-rank steps only
+        if (pl.tail_cut is not None and not self.segmented and not self.use_graph and eng.two_streams and eng.device.type == "cuda"
+                and os.environ.get("SFK_SPLIT_ADAM", "1") != "0"):
+            ops["adam_main"], ops["adam_tail"] = eng.adam_split_ops(pl.tail_cut[1], self.lr, self.betas, self.eps)
         return ops
 
     def _eager(self, pl, ops):
@@ -86,6 +90,21 @@ class TrainStep:
         ops["zero_loss"](st)
         ops["loss"](st)
         ops["zero_grad"](st)
+        if "adam_main" in ops:
+            # everything but the fast stem's filter gradient; the trunk joins the other lanes as they stand, updates the
+            # arena above the stems' filters while that last kernel runs on the fast pathway's lane, then the rest
+            i_wg = pl.tail_cut[0]
+            eng._run_lanes(pl.bwd, 0, i_wg)
+            lanes = eng.lane_streams()
+            for s_ in lanes[1:]:
+                ev = torch.cuda.Event()
+                ev.record(s_)
+                lanes[0].wait_event(ev)
+            ops["adam_main"](st)
+            torch.sub(eng.adam_step, 1, out=eng.adam_step_tail)      # (the tail launch increments its counter: sfk_adam)
+            eng._run_lanes(pl.bwd, i_wg)
+            ops["adam_tail"](st)
+            return
         if not self.segmented:
             eng._run_lanes(pl.bwd)
         else:
