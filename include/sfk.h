@@ -482,7 +482,8 @@ typedef struct {
   int64_t pool_blocks;        /* 1<<20: grid cap of the pooling kernels (one pass per thread below it)            */
   int32_t igemm_tile256;      /* 3:    bit 0: 256 x 256 tile (one workgroup per CU) for MFMA-bound layers with 256 outputs;
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
-  int32_t wgrad_target_gen;   /* 768:  ... of the register-staged filter-gradient kernels (0 = 1024)               */
+  int32_t wgrad_target_gen;   /* 512:  ... of the register-staged filter-gradient kernels (0 = 1024); round 3: 768 -> 512,
+                                         -0.15 ms per step on two boxes (fewer, longer workgroups on the side lanes)   */
   int32_t wgrad_target_256;   /* 0:    workgroups (tiles x pixel splits, at most; 256 = one per CU) of the 256-column
                                          filter-gradient tile; 0 = never use that tile.  Off by default: alone on the chip it is
                                          25..29 % faster on res4 (684 vs 532 TFLOP/s), but a workgroup owns its whole CU (96 KB of
