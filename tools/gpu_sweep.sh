@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B sweep of tuning knobs on ONE box: every configuration = one default bench run (10 steps); baseline first, last and in the middle.
+# usage: bash tools/gpu_sweep.sh "name VAR=val [VAR=val]" ...   (a baseline run is interleaved every four configurations)
 set -u
 mkdir -p gpurun_out
 run() { name=$1; shift
@@ -7,15 +8,11 @@ run() { name=$1; shift
   if [ $rc -ne 0 ]; then echo "$name failed $rc"; tail -n 3 gpurun_out/sw_$name.log; return 0; fi
   echo "$name: $(tail -n 1 gpurun_out/sw_$name.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"
 }
-run base
-run wgtg_256 SFK_WGTG=256
-run wgtg_384 SFK_WGTG=384
-run wgtg_512 SFK_WGTG=512
-run wgtg_640 SFK_WGTG=640
-run base_mid
-run bnparts_2048 SFK_BN_PARTS=2048
-run bnparts_4096 SFK_BN_PARTS=4096
-run wgtg512_bn2048 SFK_WGTG=512 SFK_BN_PARTS=2048
-run wgtg384_bn2048 SFK_WGTG=384 SFK_BN_PARTS=2048
-run wgtg512_b SFK_WGTG=512
+i=0
+run base_0
+for cfg in "$@"; do
+  run $cfg
+  i=$((i+1))
+  if [ $((i % 4)) -eq 0 ]; then run base_$i; fi
+done
 run base_end
