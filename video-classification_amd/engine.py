@@ -144,6 +144,10 @@ class Engine:
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
         self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
         self.tail_dual = os.environ.get("SFK_TAIL_DUAL", "1") != "0"     # sfk_conv_pw_dual for the narrowest block tails
+        # projection shortcuts beside branch2 on the pathway's filter-gradient lane: f = forward (default: that lane is idle in the
+        # forward, +0.5 %), b = backward too (the lane carries the filter gradients there: -0.7 %), 1 = both, 0 = neither
+        _sc = os.environ.get("SFK_SHORTCUT_LANE", "f")
+        self.shortcut_lane_f, self.shortcut_lane_b = _sc in ("1", "f"), _sc in ("1", "b")
         # diagnostic: kernel classes (OpList meta kinds, comma separated) that the lane scheduler SKIPS -- what does the step time
         # owe to one class?  (tools/gpu_ablate.sh; results are garbage with anything skipped)
         self._ablate_kinds = frozenset(k for k in os.environ.get("SFK_ABLATE", "").split(",") if k)
@@ -803,13 +807,25 @@ class Engine:
         La, Lb, Lc = (self._layers[b.conv_key] for b in (blk.conv_a, blk.conv_b, blk.conv_c))
         rec1 = None
         y1 = s1 = h1 = None
+        sl = None          # lane of the projection shortcut when it runs beside branch2 (below)
         if blk.branch1 is not None:
             L1 = self._layers[blk.branch1.conv_key]
+            # The projection shortcut (conv + BatchNorm statistics) only meets branch2 at the block's last op: on the
+            # four-lane training schedule it runs on the pathway's filter-gradient lane (idle in the forward) instead of in
+            # front of conv_a on the pathway's own chain -- the trunk is the step's critical path
+            home = pl.fwd.cur_lane
+            if self.shortcut_lane_f and train and self.two_streams and self.wgrad_lanes and self.device.type == "cuda":
+                sl = home + 2
+                pl.fwd.sync(sl, home)
+                pl.fwd.cur_lane = sl
             y1, s1, h1, rec1 = self._unit_fwd(pl, L1, x, f"{tag}.b1", train, n)
+            pl.fwd.cur_lane = home
         ya, sa, ha, reca = self._unit_fwd(pl, La, x, f"{tag}.a", train, n)
         aa = self._fmap(f"a.{tag}.a", n, ya.t, ya.h, ya.w, La.c)
         self._apply(pl, ya, sa, ha, None, None, None, True, aa)
         yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n)
+        if sl is not None:
+            pl.fwd.sync(pl.fwd.cur_lane, sl)          # the shortcut map and its coefficients are ready
         if self._tail_ok(Lc):
             assert (yb.t, yb.h, yb.w, Lc.c) == (out.t, out.h, out.w, out.c)
             res, rs, rh = (y1, s1, h1) if blk.branch1 is not None else (x, None, None)
@@ -860,6 +876,20 @@ class Engine:
                 self._bn_bwd(pl, recc, d_out, f"{tag}.c", True, out, True, dyc, reduced=reduced_c, bits=bits)
             self._wgrad(pl, recc, dyc)
             red_b = self._dgrad(pl, recc, dyc, dab, accumulate=False, fuse=(recb, None, True, f"{tag}.b"))
+        # projection shortcut: its BatchNorm backward only needs dz (final by now: the conv_c part above masked / consumed it)
+        # and only meets branch2 at the last data-gradient pass -- on the four-lane schedule it runs on the pathway's
+        # filter-gradient lane into a buffer of its own instead of in place at the end of the pathway's chain
+        sc_lane, dy1 = None, None
+        if rec1 is not None and self.shortcut_lane_b and self.two_streams and self.wgrad_lanes and not self.wgrad_one_lane \
+                and self.device.type == "cuda":
+            home = pl.bwd.cur_lane
+            sc_lane = home + 2
+            dy1 = self._fmap(f"dy.{tag}.b1", n, d_out.t, d_out.h, d_out.w, d_out.c)
+            pl.bwd.sync(sc_lane, home)
+            pl.bwd.cur_lane = sc_lane
+            self._bn_bwd(pl, rec1, d_out, f"{tag}.b1", False, None, False, dy1)
+            pl.bwd.cur_lane = home
+            self._wgrad(pl, rec1, dy1)
         self._bn_bwd(pl, recb, dab, f"{tag}.b", True, None, False, dab, reduced=red_b)
         self._wgrad(pl, recb, dab)
         daa = self._fmap(f"da.{tag}.a", n, reca.y.t, reca.y.h, reca.y.w, reca.y.c)
@@ -879,9 +909,13 @@ class Engine:
             return d_out, red_prev
         dx = self._fmap(f"dx.{tag}", n, x.t, x.h, x.w, x.c)
         self._dgrad(pl, reca, daa, dx, accumulate=False)
-        self._bn_bwd(pl, rec1, d_out, f"{tag}.b1", False, None, False, d_out)   # d_out already holds dz
-        self._wgrad(pl, rec1, d_out)
-        self._dgrad(pl, rec1, d_out, dx, accumulate=True)
+        if sc_lane is not None:
+            pl.bwd.sync(pl.bwd.cur_lane, sc_lane)      # the shortcut's BatchNorm backward ran beside branch2 (above)
+        else:
+            self._bn_bwd(pl, rec1, d_out, f"{tag}.b1", False, None, False, d_out)   # d_out already holds dz
+            self._wgrad(pl, rec1, d_out)
+            dy1 = d_out
+        self._dgrad(pl, rec1, dy1, dx, accumulate=True)
         return dx, None
 
     def _stage_bwd(self, pl, brecs, d: FMap) -> FMap:
