@@ -38,8 +38,9 @@ extern "C" {
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256; 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
- * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual. */
-#define SFK_ABI_VERSION 13
+ * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
+ * sfk_conv_igemm_family value 4. */
+#define SFK_ABI_VERSION 14
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -159,7 +160,8 @@ int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out
 int sfk_conv_epilogue_supported(const sfk_conv_desc* d); /* 1 if d's ep (as filled in) can run, else 0 */
 /* which kernel family sfk_conv_igemm runs for d (for tests / reports; never changes results beyond fp32 summation order):
  * 0 register-staged implicit GEMM, 1 LDS-DMA implicit GEMM, 3 the streaming pointwise kernel with the fused output transform
- * (conv_pw.hip: filter resident in LDS, no activation staging); < 0: invalid descriptor */
+ * (conv_pw.hip: filter resident in LDS, no activation staging), 4 the deep-pipelined 256 x 256 tile (conv_igemm_p8.hip);
+ * < 0: invalid descriptor */
 int sfk_conv_igemm_family(const sfk_conv_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -489,6 +491,10 @@ typedef struct {
                                          25..29 % faster on res4 (684 vs 532 TFLOP/s), but a workgroup owns its whole CU (96 KB of
                                          LDS, 8 x 256 VGPRs), so beside the trunk's kernels the STEP loses 1.4 %             */
   int32_t wgrad_min_stages_256; /* 48: ... which runs only where a workgroup then still has this many 32-pixel stages        */
+  int32_t igemm_p8;           /* 1:    bit 0: the deep-pipelined 256 x 256 conv tile (one workgroup per CU, 64-channel K-tiles, LDS-DMA
+                                         in flight across the barriers, wave groups half a phase apart) for the MFMA-bound
+                                         layers; bit 1: 224 computed rows per tile where that needs fewer row-generations   */
+  int32_t wgrad_p8;           /* 0:    the same structure for the MFMA-bound filter gradients (split over the pixel axis)   */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

@@ -212,6 +212,91 @@ def test_conv_filter_gradient_wide_tile_bf16(hip, case):
     assert not hip.conv_wgrad_wants_workspace(small)
 
 
+P8_CASES = [
+    # cin, cout, k, s, p, (n, t, h, w)             conv_igemm_p8.hip: 256 x 256 tile, 64-channel K-tiles, staggered wave groups
+    (256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 4, 64, 64)),     # exactly 256 tiles, 3 taps x 4 K-tiles (even count)
+    (192, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 57, 61)),     # 9 taps x 3 K-tiles = 27 (odd), ragged M, padding on every side
+    (64, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 3, 90, 94)),      # one K-tile per tap, stride 2 (strided data gradient passes), 2 co tiles
+    (512, 640, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 50, 52)),     # pointwise, 8 K-tiles, ragged co tile (640 = 2.5 tiles)
+    (192, 1024, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 9, 48, 40)),    # 4 co tiles share a pixel tile, 224-row tiles (68 x 4 vs 78 x 4)
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 64, 66)),     # 9 taps x 4 K-tiles forward AND data gradient on the tile
+]
+
+
+@pytest.mark.parametrize("case", P8_CASES, ids=[f"c{c[0]}-{c[1]}-k{''.join(map(str, c[2]))}-s{''.join(map(str, c[3]))}" for c in P8_CASES])
+def test_conv_p8_tile_bf16(hip, case):
+    """conv_igemm_p8_kernel (sfk_tuning.igemm_p8): forward with BatchNorm partial sums into a channel slice, the data gradient
+    (plain and +=, strided parity passes) and the ReLU-bitmap epilogue, against the CPU restatement; two runs agree bit for bit
+    (the staggered barrier schedule has no data-dependent order)."""
+    from video_classification_amd._lib import tuning
+    if not tuning().igemm_p8:
+        pytest.skip("the deep-pipelined tile is off in this process (SFK_P8=0)")
+    cin, cout, k, s, p, (n, t, h, w) = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(31 + cin + cout)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, k, s, p)
+    sp = fwd_pass(g, (t, h, w))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    wt = mk((cout * g.wtaps * cin,), dtype, gen, scale=(g.wtaps * cin) ** -0.5)
+    outs = []
+    for rep in range(2):
+        yc, yg = fmap_pair(n, cout, *sp.rows, dtype, torch.Generator().manual_seed(5), ld=cout + 8, c_off=8, fill=3.0)
+        pc = ConvPass(xc, yc, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, g.wtaps, cin, cout)
+        pg = ConvPass(xg, yg, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(DEV), g.wtaps, cin, cout)
+        assert hip.conv_family(pg) == 4
+        mt, mtc = hip.conv_igemm_mtiles(pg), emu.conv_igemm_mtiles(pc)
+        pc.stats = torch.zeros(mtc * cout * 2)
+        pg.stats = torch.full((mt * cout * 2,), float("nan"), device=DEV)
+        if rep == 0:
+            emu.conv_igemm(pc)(0)
+        hip.conv_igemm(pg)(stream())
+        torch.cuda.synchronize()
+        outs.append((yg.buf.cpu(), pg.stats.cpu()))
+        if rep == 0:
+            assert rel_err(yg.view5().float().cpu(), yc.view5().float()) < TOL[dtype]
+            assert torch.all(yg.buf.cpu().float().view(-1, cout + 8)[:, :8] == 3.0)
+            sg, sc = pg.stats.cpu().view(mt, cout, 2), pc.stats.view(mtc, cout, 2)
+            assert torch.isfinite(sg).all() and rel_err(sg.sum(0), sc.sum(0)) < 1e-4
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1], outs[1][1])
+    # data gradient: x <- dy (cout channels) through the transposed filter; plain, then +=
+    od = g.out_dims((t, h, w))
+    passes, _ = dgrad_passes(g, (t, h, w))
+    dyc, dyg = fmap_pair(n, cout, *od, dtype, gen)
+    wtt = mk((cin * g.wtaps * cout,), dtype, gen, scale=(g.wtaps * cout) ** -0.5)
+    for accumulate in (False, True):
+        dxc, dxg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=0)
+        if not accumulate:
+            dxc.view5().zero_(); dxg.view5().zero_()
+        fams = set()
+        for sp_ in passes:
+            emu.conv_igemm(ConvPass(dyc, dxc, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wtt, g.wtaps, cout, cin,
+                                    accumulate=accumulate))(0)
+            pgd = ConvPass(dyg, dxg, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wtt.to(DEV), g.wtaps, cout, cin,
+                           accumulate=accumulate)
+            fams.add(hip.conv_family(pgd))
+            hip.conv_igemm(pgd)(stream())
+        torch.cuda.synchronize()
+        assert rel_err(dxg.view5().float().cpu(), dxc.view5().float()) < TOL[dtype], (accumulate, fams)
+        assert torch.equal(dxg.buf.cpu().float().view(-1, cin + 8)[:, cin:], dxc.buf.float().view(-1, cin + 8)[:, cin:])
+    # output ReLU bitmap (+=): stride-1 layers only
+    if s == (1, 1, 1):
+        px = n * t * h * w
+        base = mk((px * (cout + 8),), dtype, gen)
+        keep = torch.rand(px, cout, generator=gen) > 0.45
+        bits = (keep.reshape(px, cout // 8, 8).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8).reshape(-1)
+        ya, yb = FMap(base.clone().to(DEV), n, t, h, w, cout, cout + 8, 0), FMap(base.clone().to(DEV), n, t, h, w, cout, cout + 8, 0)
+        plain = ConvPass(xg, ya, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(DEV), g.wtaps, cin, cout, accumulate=True)
+        masked = ConvPass(xg, yb, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(DEV), g.wtaps, cin, cout, accumulate=True,
+                          relu_out_bits=bits.to(DEV))
+        assert hip.conv_family(masked) == 4
+        hip.conv_igemm(plain)(stream()); hip.conv_igemm(masked)(stream())
+        torch.cuda.synchronize()
+        want = ya.buf.cpu().view(px, cout + 8).clone()
+        want[:, :cout] = torch.where(keep, want[:, :cout], torch.zeros((), dtype=dtype))
+        assert torch.equal(yb.buf.cpu().view(px, cout + 8).view(torch.int16), want.view(torch.int16))
+
+
 def test_conv_rejects_bad_descriptors(hip):
     from video_classification_amd._lib import SfkError
     gen = torch.Generator().manual_seed(0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Micro-benchmark of ONE conv layer of the metric model through the C ABI (for rocprofv3 --pmc runs).
+"""Micro-benchmark of ONE conv layer of the metric model through the C ABI (for rocprofv3 --pmc runs); custom shapes: fwd_x1024,256,3,1,1,32,8,16,16
 usage: python tools/bench_layer.py <kind> [reps]   kind in fwd_a4, fwd_b4, fwd_c4, wgrad_a4, wgrad_b4, dgrad_a4, fwd_c2"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,9 +26,14 @@ LAYERS = {  # cin, cout, k, s, p, (t, h, w)     batch 32
 }
 kind = sys.argv[1] if len(sys.argv) > 1 else "fwd_a4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-op, name = kind.split("_")
-cin, cout, k, s, p, dims = LAYERS[name]
+op, name = kind.split("_", 1)
 n = 32
+if name.startswith("x"):            # custom: x<cin>,<cout>,<kt>,<kh>,<kw>,<n>,<t>,<h>,<w>  (stride 1, same padding)
+    v = [int(a) for a in name[1:].split(",")]
+    cin, cout, k, dims, n = v[0], v[1], tuple(v[2:5]), tuple(v[6:9]), v[5]
+    s, p = (1, 1, 1), tuple(a // 2 for a in k)
+else:
+    cin, cout, k, s, p, dims = LAYERS[name]
 be = HipBackend()
 dev = "cuda"
 g = ConvGeom(cin, cout, k, s, p)
