@@ -39,9 +39,16 @@ FUSED_IDEAL_GB_PER_STEP = 0.791 * 3 * 32   # fully fused
 
 def pmc_summary():
     """The newest committed PMC summary (tools/gpu_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over
-    this very command, gfx950 correction applied) -> (dict, path relative to the repo) or (None, None)."""
+    this very command, gfx950 correction applied) -> (dict, path relative to the repo) or (None, None).  Newest = highest
+    (round, version) of profiles/rNN_vM_pmc_traffic.json; the summary records the source-tree hash it was measured on
+    (tools/tree_hash.py) and the caller labels it stale when that is not the tree this run comes from."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    import re
+
+    def key(path):
+        m = re.search(r"r(\d+)_v(\d+)_pmc_traffic", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=key)
     if not files:
         return None, None
     try:
@@ -49,6 +56,16 @@ def pmc_summary():
             return json.load(f), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError):
         return None, None
+
+
+def pmc_is_stale(summ) -> bool:
+    """True when the PMC summary was measured on another source tree than the one this process runs (or does not say)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from tree_hash import tree_hash
+        return summ.get("tree") != tree_hash()
+    except Exception:
+        return True
 
 
 def pmc_traffic(kind: str):
@@ -204,9 +221,12 @@ def main():
                          "a diagnostic of what the fifth stream costs, the line is marked and is not the metric")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-stages", action="store_true", help="also report every kernel class timed alone on one stream")
+    ap.add_argument("--ablate", default="", help="TIMING DIAGNOSTIC: comma-separated kernel classes (stage names, or laneN) the lane "
+                    "scheduler skips -- the step's results are garbage and the line says so (tools/gpu_ablate.sh)")
     args = ap.parse_args()
 
     from video_classification_amd import dist as sdist
+    from video_classification_amd.engine import EngineOptions
     from video_classification_amd.slowfast import pack_pathway_index, slowfast_r50_8x8
     from video_classification_amd.train import TrainStep
 
@@ -215,7 +235,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    model = slowfast_r50_8x8(args.classes, dtype=torch.bfloat16, device=dev, seed=0)
+    # experiment switches: read from the environment HERE, explicitly (tools/gpu_ab_env.sh); the engine itself never does
+    options = EngineOptions.from_env()
+    if args.ablate:
+        options.ablate_kinds = frozenset(k for k in args.ablate.split(",") if k)
+    model = slowfast_r50_8x8(args.classes, dtype=torch.bfloat16, device=dev, seed=0, options=options)
     model.train()
     eng = model.engine
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -259,6 +283,11 @@ def main():
                    "params": eng.num_parameters()},
         "loss_after": round(final_loss, 4),
     }
+    if options.non_default():
+        line["engine_options"] = {k_: (sorted(v) if isinstance(v, frozenset) else v) for k_, v in options.non_default().items()}
+    if options.ablate_kinds:
+        line["WARNING"] = ("TIMING DIAGNOSTIC, NOT THE METRIC: the scheduler skipped the kernel classes " + ",".join(sorted(options.ablate_kinds))
+                           + " -- the step computed garbage; only ms_per_step means anything")
     if world == 1 and args.rehearse_comm:
         line["rehearsal"] = ("NOT the metric: the N = 8 backward schedule on one GPU with a local stand-in for every all-reduce "
                              "bucket (dist.LoopbackReducer); GPU_MAX_HW_QUEUES=" + os.environ.get("GPU_MAX_HW_QUEUES", "default"))
@@ -309,15 +338,21 @@ def main():
             line["roofline"] = dict({"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                                      "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}, **common)
         line["roofline"]["traffic"], src = pmc_traffic(dom)
+        summ, _ = pmc_summary()
+        stale = pmc_is_stale(summ) if summ else None
         if src:
             line["roofline"]["traffic_source"] = src + " (rocprofv3 --pmc passes over this command; not re-measured in this run)"
+            line["roofline"]["traffic_stale"] = stale      # True: measured on another source tree than this run's
         # chip level: all HBM bytes of a step (PMC) over the step time, against the 8 TB/s spec and the fused-ideal bytes
         summ, src = pmc_summary()
         if summ:
             cls = summ.get("classes", {})
-            # one-off fills / allocations of the first step are excluded: per-step bytes of the recurring kernel classes
-            per_step = sum(c["hbm_bytes_per_step"] for k_, c in cls.items() if k_ != "other")
-            line["chip"] = {"pmc_hbm_bytes_per_step": int(per_step), "pmc_source": src,
+            # EVERY recurring kernel of a steady-state step (tools/traffic_agg.py: the window between two softmax_ce kernels; the
+            # torch-side fills are class `fill`, anything unclassified is `other` and fails the tool above 1 % of the bytes).
+            # Summaries of rounds 1-3 averaged over the profiled steps instead and carried first-step one-offs in `other`: there
+            # `other` stays excluded.
+            per_step = sum(c["hbm_bytes_per_step"] for k_, c in cls.items() if k_ != "other" or "window" in summ)
+            line["chip"] = {"pmc_hbm_bytes_per_step": int(per_step), "pmc_source": src, "pmc_stale": stale,
                             "hbm_frac_of_step": round(per_step / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4),
                             "bytes_vs_fused_ideal": round(per_step / (FUSED_IDEAL_GB_PER_STEP * 1e9), 3),
                             "fused_ideal_GB_per_step": round(FUSED_IDEAL_GB_PER_STEP, 1),

@@ -196,7 +196,7 @@ typedef struct {
 int sfk_conv_wgrad(const sfk_wgrad_desc* d, sfk_stream_t stream);
 int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d); /* host-side query; <0 on error */
 int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d);        /* the fused data gradient (dg_w / dg_y) can run */
-/* 1 when d would run the 256-column tile of the MFMA-bound layers, which sums its pixel splits ONLY through `workspace`
+/* 1 when d would run one of the 256-column tiles of the MFMA-bound layers, which sum their pixel splits ONLY through `workspace`
  * (sfk_conv_wgrad_workspace_bytes(d) bytes; without it the call still works, on the 128-column tile with atomics) */
 int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d);
 
@@ -494,7 +494,9 @@ typedef struct {
   int32_t igemm_p8;           /* 1:    bit 0: the deep-pipelined 256 x 256 conv tile (one workgroup per CU, 64-channel K-tiles, LDS-DMA
                                          in flight across the barriers, wave groups half a phase apart) for the MFMA-bound
                                          layers; bit 1: 224 computed rows per tile where that needs fewer row-generations   */
-  int32_t wgrad_p8;           /* 0:    the same structure for the MFMA-bound filter gradients (split over the pixel axis)   */
+  int32_t wgrad_p8;           /* 0:    the same structure for the MFMA-bound filter gradients (pixel axis split over workgroups, partial
+                                         tiles through the workspace): on for layers where a workgroup then still runs this many
+                                         64-pixel K-tiles; 0 = off                                                         */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

@@ -17,7 +17,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "pass $ctr exit $rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: stopping"; exit $rc; fi
 done
-python tools/traffic_agg.py $OUT $((STEPS+WARM)) > gpurun_out/pmc_traffic.json
+python tools/traffic_agg.py $OUT $(python tools/tree_hash.py) > gpurun_out/pmc_traffic.json
 rc=$?
 head -c 1500 gpurun_out/pmc_traffic.json; echo
 # the raw per-dispatch tables are large; keep only the aggregate

@@ -9,45 +9,18 @@
 // The (tap, cin) axis is flattened into the GEMM's column space and gathered per 16-byte segment (as the forward
 // kernel packs its K axis), so the taps of narrow layers share one tile and dY is read once per column tile.
 // Grid = (co-tile x column-tile, 1, pixel-split); partial tiles are combined with fp32 atomics into dW.
-#include "sfk_common.h"
-#include <stdlib.h>
 
-namespace {
+#include "conv_wgrad_common.h"
 
-struct WgradK {
-  const void* x;
-  const void* dy;
-  float* dw;
-  int xt, xh, xw, xld, xoff;
-  int dld, doff;
-  int M;
-  FastDiv drw, drh, drt;
-  int gst, gsh, gsw;
-  int cin, cout, wtaps, ntaps;
-  int citiles;                    // column tiles over the flattened (tap, cin) axis
-  int chunks_per_split, nchunks;  // in stages of KS*32 pixels
-  FastDiv dspt, dcin;             // 16-byte segments per tap; channels per tap
-  uint32_t xbytes, dbytes;        // extents of the buffer resources
-  float4* ws;                     // partial-tile workspace (NULL: fp32 atomics straight into dw)
-  int ntiles;                     // cotiles * citiles
-  const void* dgw;                // fused data gradient (DG kernels): [cin][cout] matrix, output map
-  void* dgy;
-  int dgld, dgoff;
-  sfk_tap taps[SFK_MAX_TAPS];
-};
+using namespace sfk_wgrad;
 
-constexpr int MK = 32;  // pixels per K-step
-
-// XCD-aware block order (as conv_igemm): blocks b, b+8, ... share an L2, so consecutive LOGICAL ids go to one XCD and the
-// tiles of one pixel split (which read the same dY rows and overlapping X rows) are neighbours there.
-__device__ __forceinline__ void wg_block(int ntiles, int& tile, int& split) {
-  const int nblk = gridDim.x, b = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  tile = logical % ntiles;
-  split = logical / ntiles;
+namespace sfk_wgrad {
+// conv_wgrad_p8.hip: the deep-pipelined 256 x 256 tile of the MFMA-bound layers (dry != NULL: workspace bytes only)
+__attribute__((visibility("hidden"))) int launch_wgrad_p8(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry);
+__attribute__((visibility("hidden"))) bool wgrad_p8_ok(const sfk_wgrad_desc* d, int M);
 }
 
+namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -569,61 +542,6 @@ __global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void
   }
 }
 
-// Second pass of the workspace path: dw[co][widx][ci] += sum over pixel splits of the partial tiles, in split order
-// (deterministic; fp32 atomics moved ~1.3 TB/s chip-wide and every split re-adds the whole tile).
-// NWV waves per block laid out as WCO x (NWV/WCO), FO x FI accumulator fragments per wave.
-template <int NWV, int WCO, int FO, int FI>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK k, int splits) {
-  constexpr int PER_TILE = NWV * FO * FI * 64;          // float4 per tile
-  constexpr int TCO = WCO * 16 * FO, TCI = (NWV / WCO) * 16 * FI;
-  // 16 consecutive float4 (256 B) per block x 16 split groups; group zg adds splits zg, zg+16, ... in order, then the
-  // 16 group sums are added in order: the summation tree is fixed, whatever the launch does
-  __shared__ float4 red[16][16];
-  const int l16 = threadIdx.x & 15, zg = threadIdx.x >> 4;
-  const int64_t idx = (int64_t)blockIdx.x * 16 + l16;
-  const int64_t total = (int64_t)k.ntiles * PER_TILE;
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (idx < total) {
-    const float4* p = k.ws + idx;
-#pragma unroll 4
-    for (int z = zg; z < splits; z += 16) {
-      const float4 v = p[(int64_t)z * total];
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-    }
-  }
-  red[zg][l16] = sum;
-  __syncthreads();
-  if (zg != 0 || idx >= total) return;
-#pragma unroll
-  for (int z = 1; z < 16; ++z) {
-    const float4 v = red[z][l16];
-    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-  }
-  const int tile = (int)(idx / PER_TILE), e = (int)(idx % PER_TILE);
-  const int lane = e & 63, frag = (e >> 6) % (FO * FI), wave = (e >> 6) / (FO * FI);
-  const int i = frag / FI, j = frag % FI, wco = wave % WCO, wci = wave / WCO;
-  const int cot = tile / k.citiles, cit = tile % k.citiles;
-  const int col = cit * TCI + wci * 16 * FI + 16 * j + (lane & 15);
-  uint32_t tap, ci;
-  k.dcin.divmod((uint32_t)col, tap, ci);
-  if (tap >= (uint32_t)k.ntaps) return;
-  const int widx = k.taps[tap].widx;
-  const int co0 = cot * TCO + wco * 16 * FO + 16 * i + 4 * (lane >> 4);
-  const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (co0 + r < k.cout) k.dw[((int64_t)(co0 + r) * k.wtaps + widx) * k.cin + ci] += v4[r];
-}
-
-template <int NWV, int WCO, int FO, int FI>
-int launch_reduce(const WgradK& k, int splits, hipStream_t s) {
-  constexpr int PER_TILE = NWV * FO * FI * 64;
-  const int64_t total = (int64_t)k.ntiles * PER_TILE;
-  hipLaunchKernelGGL((wgrad_reduce_kernel<NWV, WCO, FO, FI>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, k, splits);
-  SFK_CHECK_LAUNCH();
-  return SFK_OK;
-}
-
 template <int TCO, int NW, bool DG = false, int TCI = 128, int NS = 3>
 int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   const int cols = d->ntaps * d->cin;
@@ -747,6 +665,10 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
   k.dgw = nullptr; k.dgy = nullptr; k.dgld = 0; k.dgoff = 0;
   const int cols = d->ntaps * d->cin;
   if constexpr (sizeof(T) == 2) {
+    if ((dry || k.ws) && wgrad_p8_ok(d, k.M)) {      // the deep-pipelined 256 x 256 tile (conv_wgrad_p8.hip); workspace only
+      const int r = launch_wgrad_p8(k, d, s, dry);
+      if (r != SFK_ERR_UNSUPPORTED) return r;
+    }
     const int wt = (!d->dg_w && (dry || k.ws)) ? wide_tile_co(d, k.M) : 0;
     if (wt) {       // (no workspace / too small a one: SFK_ERR_UNSUPPORTED, and the 128-column tile below runs with atomics)
       const int r = launch_dma<256, 8, false, 256>(k, d, s, dry);
@@ -801,7 +723,8 @@ extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
 
 extern "C" int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d) {
   if (!d || validate(d) != SFK_OK || d->dg_w) return 0;
-  return wide_tile_co(d, (int)sfk_fmap_pixels(&d->dy)) ? 1 : 0;
+  const int M = (int)sfk_fmap_pixels(&d->dy);
+  return (wgrad_p8_ok(d, M) || wide_tile_co(d, M)) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d) {

@@ -14,6 +14,7 @@ per-channel statistics, master weights, gradients and the head are fp32.
 from __future__ import annotations
 
 import math
+import dataclasses
 import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
@@ -123,9 +124,62 @@ class Plan:
         return segs
 
 
+@dataclasses.dataclass
+class EngineOptions:
+    """Every schedule / fusion switch of the engine, with the measured best as the default.  The product never reads the
+    environment: Engine() without options runs the defaults, and whoever wants an A/B (bench.py, tools/) fills an
+    EngineOptions -- EngineOptions.from_env() maps the SFK_* variables of tools/gpu_ab_env.sh onto the fields, explicitly, at
+    the caller's request.  `ablate_kinds` (timing-only: the scheduler SKIPS those kernel classes, results are garbage) has
+    no environment variable at all: bench.py --ablate sets it and says so in its output line."""
+    fuse_bn_bwd: bool = False          # BatchNorm-backward reduce in the dgrad epilogues (sfk_conv_desc.bnb): neutral .. -0.75 %
+    tail_dual: bool = True             # sfk_conv_pw_dual for the narrowest block tails
+    shortcut_lane: str = "f"           # projection shortcuts beside branch2 on the filter-gradient lane: f forward, b backward, 1 both, 0 neither
+    wgrad_lanes: int = 1               # 0: filter gradients on the pathway lanes; 1: one lane per pathway; 2: ONE lane for both
+    relu_bits: bool = True             # block-output ReLU masks kept as bitmaps
+    relu_out_mask: bool = True         # ... and applied by the data-gradient pass that finishes an identity block's output gradient
+    deterministic_wgrad: bool = False  # split sums through the workspace + ordered reduce everywhere (bit-reproducible dW)
+    fuse_tail: bool = True             # conv_c -> norm_c -> (+ shortcut) -> ReLU without the conv output in HBM
+    tail_min_c: int = 8
+    tail_max_c: int = 128
+    fuse_stem_tail: bool = True        # the stems' BatchNorm -> ReLU -> MaxPool as one forward pass / two-pass backward
+    fuse_tail_dg: bool = True          # R and the first dgrad pass of the tail backward in one kernel
+    tail_r_lane: int = 0               # R = dz^T a beside the first dgrad pass: 0 pathway lane, 2 filter-gradient lane, 4 own lanes
+    split_refresh: bool = True         # filter refresh: stems on the trunk, the rest on the idle filter-gradient lane
+    split_adam: bool = True            # Adam beside the last kernel of the step (TrainStep)
+    trunk_priority: bool = True        # the trunk lane on a high-priority HIP stream (TrainStep)
+    mfma_wgrad_trunk: bool = False     # MFMA-bound filter gradients on the pathway's own lane, directly behind their data gradient
+    dist_wgrad_one_lane: bool = True   # world > 1: all filter gradients on ONE lane, the collective's stream is the fourth queue
+    ablate_kinds: frozenset = frozenset()
+
+    _ENV = {"SFK_FUSE_BNB": ("fuse_bn_bwd", "1"), "SFK_TAIL_DUAL": ("tail_dual", "!0"), "SFK_SHORTCUT_LANE": ("shortcut_lane", "s"),
+            "SFK_WGRAD_LANES": ("wgrad_lanes", "i"), "SFK_RELU_BITS": ("relu_bits", "!0"), "SFK_RELU_OUT": ("relu_out_mask", "!0"),
+            "SFK_WGWS": ("deterministic_wgrad", "1"), "SFK_TAIL": ("fuse_tail", "!0"), "SFK_TAIL_MINC": ("tail_min_c", "i"),
+            "SFK_TAIL_MAXC": ("tail_max_c", "i"), "SFK_STEM_TAIL": ("fuse_stem_tail", "!0"), "SFK_TAIL_DG": ("fuse_tail_dg", "!0"),
+            "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"),
+            "SFK_SPLIT_ADAM": ("split_adam", "!0"), "SFK_TRUNK_PRIO": ("trunk_priority", "!0"),
+            "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0")}
+
+    @classmethod
+    def from_env(cls, env=None) -> "EngineOptions":
+        """The SFK_* experiment variables -> options (benchmark / tools only; the library and the engine never call this)."""
+        env = os.environ if env is None else env
+        o = cls()
+        for var, (field, kind) in cls._ENV.items():
+            if var not in env:
+                continue
+            v = env[var]
+            setattr(o, field, v == "1" if kind == "1" else v != "0" if kind == "!0" else int(v) if kind == "i" else v)
+        return o
+
+    def non_default(self) -> Dict[str, object]:
+        d = EngineOptions()
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)
+                if not f.name.startswith("_") and getattr(self, f.name) != getattr(d, f.name)}
+
+
 class Engine:
     def __init__(self, spec: arch.SlowFastSpec, dtype: torch.dtype = torch.bfloat16, device="cuda", backend=None,
-                 seed: int = 0):
+                 seed: int = 0, options: Optional[EngineOptions] = None):
         assert dtype in (torch.bfloat16, torch.float32)
         self.spec, self.dtype, self.device = spec, dtype, torch.device(device)
         if backend is None:
@@ -140,45 +194,48 @@ class Engine:
         self._build_params(seed)
         self.max_parts = _max_parts() if getattr(self.be, "name", "") == "hip" else 1024
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
+        # every switch comes from the options object (defaults = the measured best); nothing here reads the environment
+        o = self.options = options if options is not None else EngineOptions()
+        assert o.shortcut_lane in ("f", "b", "1", "0") and o.tail_r_lane in (0, 2, 4) and o.wgrad_lanes in (0, 1, 2)
         # BatchNorm-backward reduce folded into the dgrad epilogues (sfk_conv_desc.bnb): removes 3.3 ms of reduce kernels,
         # adds 3.0 ms to the conv class -- measured neutral on the step (877 vs 879 clips/s), so it is opt-in
-        self.fuse_bn_bwd = os.environ.get("SFK_FUSE_BNB", "0") == "1"
-        self.tail_dual = os.environ.get("SFK_TAIL_DUAL", "1") != "0"     # sfk_conv_pw_dual for the narrowest block tails
+        self.fuse_bn_bwd = o.fuse_bn_bwd
+        self.tail_dual = o.tail_dual
         # projection shortcuts beside branch2 on the pathway's filter-gradient lane: f = forward (default: that lane is idle in the
         # forward, +0.5 %), b = backward too (the lane carries the filter gradients there: -0.7 %), 1 = both, 0 = neither
-        _sc = os.environ.get("SFK_SHORTCUT_LANE", "f")
-        self.shortcut_lane_f, self.shortcut_lane_b = _sc in ("1", "f"), _sc in ("1", "b")
-        # diagnostic: kernel classes (OpList meta kinds, comma separated) that the lane scheduler SKIPS -- what does the step time
-        # owe to one class?  (tools/gpu_ablate.sh; results are garbage with anything skipped)
-        self._ablate_kinds = frozenset(k for k in os.environ.get("SFK_ABLATE", "").split(",") if k)
-        self.wgrad_lanes = os.environ.get("SFK_WGRAD_LANES", "1") != "0"   # filter gradients on their own streams
+        self.shortcut_lane_f, self.shortcut_lane_b = o.shortcut_lane in ("1", "f"), o.shortcut_lane in ("1", "b")
+        # diagnostic: kernel classes (OpList meta kinds) that the lane scheduler SKIPS -- what does the step time owe to one
+        # class?  (bench.py --ablate; results are garbage with anything skipped)
+        self._ablate_kinds = frozenset(o.ablate_kinds)
+        self.wgrad_lanes = o.wgrad_lanes != 0                               # filter gradients on their own streams
         # both pathways' filter gradients on ONE lane (lane 2): three compute streams, so that the collective's stream of a
         # world > 1 step is the fourth hardware queue (dist.GradReducer; single-rank: 1078 vs 1077 clips/s, neutral)
-        self.wgrad_one_lane = os.environ.get("SFK_WGRAD_LANES", "1") == "2"
-        self.relu_bits = os.environ.get("SFK_RELU_BITS", "1") != "0"       # block-output ReLU masks kept as bitmaps
+        self.wgrad_one_lane = o.wgrad_lanes == 2
+        self.relu_bits = o.relu_bits                                        # block-output ReLU masks kept as bitmaps
         # ... and applied by the data-gradient pass that finishes the gradient of an identity-shortcut block's output
         # (sfk_conv_desc.out_relu_bits): that block's BatchNorm backward then reads dz as it is, no mask, no rewrite
-        self.relu_out_mask = self.relu_bits and os.environ.get("SFK_RELU_OUT", "1") != "0"
+        self.relu_out_mask = self.relu_bits and o.relu_out_mask
         self.kvec = 8 if self.dtype == torch.bfloat16 else 4               # channels per 16-byte lane of the BN kernels
         # split sums of the filter gradients: fp32 atomics (default: on their own lanes the atomic latency hides behind
         # the pathway's chain, 897 vs 886 clips/s) or the partial-tile workspace + ordered reduce (bit-reproducible dW)
-        self.deterministic_wgrad = os.environ.get("SFK_WGWS", "0") == "1"
+        self.deterministic_wgrad = o.deterministic_wgrad
         # The bottleneck tail conv_c -> norm_c -> (+ shortcut) -> ReLU without the conv output in HBM (include/sfk.h,
         # sfk_bn_tail_*): statistics from the Gram matrix of conv_c's input, BatchNorm + shortcut + ReLU in the conv
         # epilogue, and a backward that needs neither y_c nor dy_c.  Per block with conv_c inputs of >= tail_min_c channels.
-        self.fuse_tail = os.environ.get("SFK_TAIL", "1") != "0" and hasattr(self.be, "bn_tail_fwd")
-        self.tail_min_c = int(os.environ.get("SFK_TAIL_MINC", "8"))
+        self.fuse_tail = o.fuse_tail and hasattr(self.be, "bn_tail_fwd")
+        self.tail_min_c = o.tail_min_c
         # upper bound: the tail's fixed cost is O(cout * c^2) (T = W G, W^T B W) whatever the map size, what it saves is
         # O(pixels * cout) -- it pays on the large maps of the early stages (c <= 128), not on res4 / res5 (c = 256 / 512)
-        self.tail_max_c = int(os.environ.get("SFK_TAIL_MAXC", "128"))
+        self.tail_max_c = o.tail_max_c
         # the stems' BatchNorm -> ReLU -> MaxPool as one forward pass and a two-pass backward (sfk_bn_maxpool_*)
-        self.fuse_stem_tail = (os.environ.get("SFK_STEM_TAIL", "1") != "0" and hasattr(self.be, "bn_maxpool_fwd")
-                               and self.be.bn_maxpool_supported(3, 2, 1))
+        self.fuse_stem_tail = (o.fuse_stem_tail and hasattr(self.be, "bn_maxpool_fwd") and self.be.bn_maxpool_supported(3, 2, 1))
         # R = dz^T a beside the first dgrad pass (_tail_bwd): 0 = on the pathway's lane (default), 2 = on its filter-gradient lane
         # (neutral), 4 = on lanes of its own (an experiment: 948 clips/s with the default 4 hardware queues, 719 with 8)
-        self.fuse_tail_dg = os.environ.get("SFK_TAIL_DG", "1") != "0"      # R and the first dgrad pass in one kernel (_tail_bwd)
-        self.tail_r_lane = int(os.environ.get("SFK_TAIL_RLANE", "0"))
-        assert self.tail_r_lane in (0, 2, 4)
+        self.fuse_tail_dg = o.fuse_tail_dg                                  # R and the first dgrad pass in one kernel (_tail_bwd)
+        self.tail_r_lane = o.tail_r_lane
+        # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway.  Not more: a process gets
+        # 4 hardware queues (GPU_MAX_HW_QUEUES), streams beyond that share one and serialise (6 lanes: 948 vs 1033 clips/s)
+        self.NLANES = 6 if o.tail_r_lane == 4 else 4
         self._side = None
         self.drop_seed = torch.full((1,), 0x5EED0000 + seed, dtype=torch.int64, device=self.device)
 
@@ -946,7 +1003,7 @@ class Engine:
             ent = lambda Ls: [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad) for L in Ls]
             stem_keys = {st.conv_key for st in W.stems}
             split = (train and NP == 2 and self.two_streams and self.wgrad_lanes and self.device.type == "cuda"
-                     and os.environ.get("SFK_SPLIT_REFRESH", "1") != "0")
+                     and self.options.split_refresh)
             if split:
                 pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key in stem_keys])))
                 refresh_lane = 2
@@ -1158,9 +1215,6 @@ class Engine:
             op(stream)
 
     _plan_serial = 0
-    # 0 slow pathway / trunk, 1 fast pathway, 2 / 3 filter gradients of the slow / fast pathway.  Not more: a process gets
-    # 4 hardware queues (GPU_MAX_HW_QUEUES), streams beyond that share one and serialise (6 lanes: 948 vs 1033 clips/s)
-    NLANES = 6 if os.environ.get("SFK_TAIL_RLANE", "0") == "4" else 4
 
     def lane_streams(self):
         """torch streams the schedule's lanes run on (one entry when the schedule is single-stream / on the CPU)"""
@@ -1228,6 +1282,9 @@ class Engine:
             self.adam_m = self._new(self.arena_numel)
             self.adam_v = self._new(self.arena_numel)
             self.adam_step = self._new(1, dtype=torch.int64)
+            # scratch counter of the split update's second launch (adam_split_ops): ONE tensor per engine, so that every cached
+            # TrainStep entry bakes in the same pointer and the value TrainStep writes before the launch is the one it reads
+            self.adam_step_tail = self._new(1, dtype=torch.int64)
 
     def adam_ops(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> Run:
         self._adam_state()
@@ -1240,7 +1297,6 @@ class Engine:
         TrainStep sets to step - 1 first).  Element-wise identical to the single launch."""
         self._adam_state()
         n = self.arena_numel
-        self.adam_step_tail = self._new(1, dtype=torch.int64)
         main = self.be.adam(self.P.data[cut:], self.G[cut:], self.adam_m[cut:], self.adam_v[cut:], n - cut, lr, betas[0],
                             betas[1], eps, grad_scale, self.adam_step, None)
         tail = self.be.adam(self.P.data[:cut], self.G[:cut], self.adam_m[:cut], self.adam_v[:cut], cut, lr, betas[0],

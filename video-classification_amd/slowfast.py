@@ -36,10 +36,10 @@ class _SlowFastFn(torch.autograd.Function):
 
 
 class SlowFast(torch.nn.Module):
-    def __init__(self, spec: arch.SlowFastSpec, dtype=torch.float32, device="cuda", backend=None, seed: int = 0):
+    def __init__(self, spec: arch.SlowFastSpec, dtype=torch.float32, device="cuda", backend=None, seed: int = 0, options=None):
         super().__init__()
         self.spec = spec
-        self.engine = Engine(spec, dtype=dtype, device=device, backend=backend, seed=seed)
+        self.engine = Engine(spec, dtype=dtype, device=device, backend=backend, seed=seed, options=options)
         self.arena = self.engine.P          # the one trainable tensor: all live parameters, kernel layout
         # PackPathway ((deprecated)/(torchvideo)train.py:53-71) as a model attribute: when set, model([frames, frames])
         # reads the slow pathway's frames frames[:, :, slow_t_index] inside the stem kernel (MODEL.ARCH canonical8x8)
@@ -99,8 +99,8 @@ def init_canonical_slowfast(cfg, device="cuda", backend=None, seed: int = 0, alp
     return m
 
 
-def slowfast_r50_8x8(num_class: int = 400, dtype=torch.bfloat16, device="cuda", backend=None, seed: int = 0) -> SlowFast:
-    return SlowFast(arch.canonical_spec(num_class), dtype=dtype, device=device, backend=backend, seed=seed)
+def slowfast_r50_8x8(num_class: int = 400, dtype=torch.bfloat16, device="cuda", backend=None, seed: int = 0, options=None) -> SlowFast:
+    return SlowFast(arch.canonical_spec(num_class), dtype=dtype, device=device, backend=backend, seed=seed, options=options)
 
 
 def slow_r50(num_class: int = 400, input_channels: int = 5, dtype=torch.float32, device="cuda", backend=None,

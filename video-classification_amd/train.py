@@ -35,9 +35,10 @@ from .slowfast import init_my_slowfast
 class TrainStep:
     """One optimisation step on one rank: forward -> mean cross-entropy -> backward -> (all-reduce) -> Adam.
 
-    Default execution is eager on two HIP streams (slow / fast pathway, engine.OpList): measured 46.5 ms/step vs
-    51.7 ms for the same schedule replayed as ONE hipGraph, whose replay serialises the two branches on this ROCm;
-    ``use_graph=True`` keeps the single-graph replay (lowest host load)."""
+    Default execution is eager on four HIP streams (engine.OpList lanes: slow pathway / trunk, fast pathway, one
+    filter-gradient lane per pathway); the same schedule captured into ONE hipGraph replays its branches one after the
+    other on this ROCm (round 1: 51.7 against 46.5 ms for two eager lanes), so ``use_graph=True`` is kept only for the
+    lowest host load.  Every switch comes from ``engine.options`` (engine.EngineOptions); nothing here reads the environment."""
 
     def __init__(self, engine: Engine, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = False,
                  reducer: Optional[sdist.GradReducer] = None, overlap_segments: int = 6):
@@ -46,8 +47,10 @@ class TrainStep:
         self.world = reducer.world if reducer is not None else 1
         self.segmented = reducer is not None and reducer.active     # cut backward into segments and exchange them as they finish
         if self.segmented:
-            # three compute lanes + the collective's own stream = the four hardware queues a process gets (dist.GradReducer)
-            engine.wgrad_one_lane = True
+            # three compute lanes + the collective's own stream = the four hardware queues a process gets (dist.GradReducer);
+            # measured only with the single-GPU stand-in (dist.LoopbackReducer), never on RCCL: options.dist_wgrad_one_lane = False
+            # keeps the four compute lanes for an A/B on a multi-GPU node
+            engine.wgrad_one_lane = engine.options.dist_wgrad_one_lane or engine.wgrad_one_lane
         self.use_graph = use_graph and not self.segmented and engine.device.type == "cuda"
         self.overlap_segments = overlap_segments
         dev = engine.device
@@ -60,7 +63,7 @@ class TrainStep:
         # HIGH-priority stream of its own so that its next kernel gets CUs ahead of the filter-gradient lanes' backlog
         # (measured +0.8 % clips/s).  The caller's stream waits for the step as before.
         self._trunk = None
-        if dev.type == "cuda" and not self.use_graph and os.environ.get("SFK_TRUNK_PRIO", "-1") != "0":
+        if dev.type == "cuda" and not self.use_graph and engine.options.trunk_priority:
             self._trunk = torch.cuda.Stream(dev, priority=-1)
 
     def reset_meters(self):
@@ -78,7 +81,7 @@ class TrainStep:
         )
         # the optimiser beside the last kernel of the step (engine.Plan.tail_cut): eager four-lane single-rank steps only
         if (pl.tail_cut is not None and not self.segmented and not self.use_graph and eng.two_streams and eng.device.type == "cuda"
-                and os.environ.get("SFK_SPLIT_ADAM", "1") != "0"):
+                and eng.options.split_adam):
             ops["adam_main"], ops["adam_tail"] = eng.adam_split_ops(pl.tail_cut[1], self.lr, self.betas, self.eps)
         return ops
 
