@@ -494,7 +494,7 @@ typedef struct {
   int32_t igemm_p8;           /* 1:    bit 0: the deep-pipelined 256 x 256 conv tile (one workgroup per CU, 64-channel K-tiles, LDS-DMA
                                          in flight across the barriers, wave groups half a phase apart) for the MFMA-bound
                                          layers; bit 1: 224 computed rows per tile where that needs fewer row-generations   */
-  int32_t wgrad_p8;           /* 0:    the same structure for the MFMA-bound filter gradients (pixel axis split over workgroups, partial
+  int32_t wgrad_p8;           /* 16:   the same structure for the MFMA-bound filter gradients (pixel axis split over workgroups, partial
                                          tiles through the workspace): on for layers where a workgroup then still runs this many
                                          64-pixel K-tiles; 0 = off                                                         */
 } sfk_tuning;

@@ -399,7 +399,12 @@ def test_small_tensor_gradients_bf16_vs_bf16_storage_oracle(ref_style):
     the bf16 engine's GRADIENT of every tensor with fewer than 64 elements against the fp32 oracle's, relative L2, held to a
     multiple of what bf16 STORAGE alone does to the oracle (_emulate_bf16_storage: same step, same dropout mask).  These are the
     tensors the column-sum (out_sums), epilogue_bits_sum and sfk_conv_pw_dual paths feed; a wrong fold or a dropped partial
-    row is O(1) here."""
+    row is O(1) here.
+    Measured on MI355X (round 4; ref / canonical): the bf16-storage ORACLE's own small-tensor gradients are 0.29 / 0.30 (median
+    relative L2, worst 0.66 / 0.38) off its fp32 run on this mini model -- the engine's are 0.32 / 0.37 (worst 0.51 / 0.53), with
+    1-3 flipped signs per tensor on elements whose |g| is 1-7 % of the tensor's largest.  That is what moved the update cosine of
+    blocks.1.multipathway_blocks.1.res_blocks.0.branch2.norm_b.bias from 0.47 to 0.24 in round 3 (a different fold order =
+    different rounding of near-zero sums), not a kernel fault: any bf16 implementation scatters these tensors by a third."""
     om, m = make_models(ref_style, dtype=torch.bfloat16, device=DEV, backend=hip_backend())
     x = make_inputs(ref_style, n=8)
     labels = torch.tensor(LABELS8)
@@ -440,27 +445,35 @@ def test_split_adam_with_alternating_label_tensors_matches_single_launch():
     """The optimiser beside the last kernel of the step (two sfk_adam launches, the second on a scratch step counter) must be the
     single launch element for element whatever the TrainStep cache does: two resident label tensors alternate on the same bound
     clips, so every cache entry is re-used after another one ran (the scratch counter used to be allocated per entry and went
-    stale on re-use: wrong bias correction for the stems' filters, silently)."""
-    from video_classification_amd.engine import EngineOptions
+    stale on re-use: wrong bias correction for the stems' filters, silently).  Checked against torch's Adam arithmetic replayed
+    on the gradients the step left in the arena -- separately for the range of each launch."""
     from video_classification_amd.train import TrainStep
     x = [t.to(DEV) for t in make_inputs(False, n=4)]
     la, lb = torch.tensor([1, 4, 0, 6]).to(DEV), torch.tensor([2, 3, 5, 1]).to(DEV)
-    om, m0 = make_models(False, dtype=torch.bfloat16, device=DEV, backend=hip_backend())
-    finals = []
-    for split in (True, False):
-        # ordered split sums of the filter gradients: the whole step is then bit-reproducible, so the two runs may only differ
-        # through the optimiser
-        m = SlowFast(m0.spec, dtype=torch.bfloat16, device=DEV, backend=hip_backend(),
-                     options=EngineOptions(split_adam=split, deterministic_wgrad=True))
-        m.load_state_dict(om.state_dict(), strict=True)
-        m.train()
-        step = TrainStep(m.engine, lr=1e-3, use_graph=False)
-        for i in range(6):
-            step(x[0], x[1], la if i % 2 == 0 else lb)
+    om, m = make_models(False, dtype=torch.bfloat16, device=DEV, backend=hip_backend())
+    eng = m.engine
+    assert eng.options.split_adam
+    m.train()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    step = TrainStep(eng, lr=lr, betas=(b1, b2), eps=eps, use_graph=False)
+    P = eng.P.data.clone().double()
+    mom, var = torch.zeros_like(P), torch.zeros_like(P)
+    for i in range(6):
+        step(x[0], x[1], la if i % 2 == 0 else lb)
         torch.cuda.synchronize()
-        finals.append((m.engine.P.data.clone().cpu(), int(m.engine.adam_step[0]), len(step._cache)))
-    assert finals[0][1] == finals[1][1] == 6 and finals[0][2] == 2          # two cache entries, each re-used after the other ran
-    assert torch.equal(finals[0][0], finals[1][0])
+        g = eng.G.double()                                   # this step's gradients (zeroed at the start of the NEXT step)
+        t = i + 1
+        mom = b1 * mom + (1 - b1) * g
+        var = b2 * var + (1 - b2) * g * g
+        P = P - lr * (mom / (1 - b1 ** t)) / ((var / (1 - b2 ** t)).sqrt() + eps)
+        assert int(eng.adam_step[0]) == t and int(eng.adam_step_tail[0]) == t
+        cut = eng._plan_for(x[0], x[1], None, True).tail_cut[1]
+        got = eng.P.data.double()
+        for name, sl in (("tail (stem filters)", slice(0, cut)), ("main", slice(cut, None))):
+            err = float((got[sl] - P[sl]).abs().max())
+            assert err < 2e-6, (name, t, err)
+        P = got.clone()                                      # follow the engine's fp32 rounding
+    assert len(step._cache) == 2                             # two entries, each re-used after the other ran
 
 
 @pytest.mark.parametrize("ref_style,depth", [(True, 18), (False, 18), (True, 26), (False, 26)],
@@ -703,7 +716,9 @@ def test_metric_geometry_train_step_bf16_at_the_bench_batch():
     assert abs(loss_m - loss_o) < 5e-3 * loss_o
     # (the unbiased running variance carries n / (n - 1) of a 16 times larger n: <= 1.2e-3 on the smallest maps)
     assert rm < 1e-2 and rv < 1e-2, (rm, rv)
-    assert np.median(cos) > 0.90 and np.percentile(cos, 10) > 0.85 and cos.min() > 0.6, (np.median(cos), rows[:5])
+    # (without the dropout the 8-element fast-stem BatchNorm bias is the worst tensor of the bf16-STORAGE ORACLE too: 0.560 against
+    # its own fp32 run, engine 0.600 -- the floor follows the yardstick)
+    assert np.median(cos) > 0.90 and np.percentile(cos, 10) > 0.85 and cos.min() > min(0.6, cos_e.min() - 0.05), (np.median(cos), rows[:5])
     assert np.median(cos) > np.median(cos_e) - 0.03 and np.percentile(cos, 10) > np.percentile(cos_e, 10) - 0.05
     assert all(0.4 < r[1] < 2.0 for r in rows), [r for r in rows if not 0.4 < r[1] < 2.0][:5]
     # ... and this batch really runs the big tiles: slow res4 conv_a (1024 -> 256, (3,1,1), 8 x 14 x 14) on the LDS-DMA family or the

@@ -525,11 +525,16 @@ class Engine:
         # dependency chain (BN backward -> dgrad -> BN backward ...) for a lane of their own and fill the gaps that chain
         # leaves on the chip; the lane waits for the producer of dy, everything joins before the optimiser.
         home = pl.bwd.cur_lane
+        wants = hasattr(self.be, "conv_wgrad_wants_workspace") and self.be.conv_wgrad_wants_workspace(wp)
         wl = (2 if self.wgrad_one_lane else home + 2) if self.wgrad_lanes else home
+        # the MFMA-bound layers' 256 x 256 tiles own every CU they run on (one workgroup per CU): options.mfma_wgrad_trunk keeps
+        # them on the pathway's own lane, directly behind the data gradient that read the same dY (still in L2 / MALL), instead of
+        # beside the trunk's kernels
+        if wants and self.options.mfma_wgrad_trunk:
+            wl = home
         if wl != home:
             pl.bwd.sync(wl, home)
             pl.bwd.cur_lane = wl
-        wants = hasattr(self.be, "conv_wgrad_wants_workspace") and self.be.conv_wgrad_wants_workspace(wp)
         need = self.be.conv_wgrad_workspace_bytes(wp) if (self.deterministic_wgrad or wants) else 0
         if need > 0:
             cap = self._wg_ws_need.get(wl, 0)
