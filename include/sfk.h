@@ -39,8 +39,8 @@ extern "C" {
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256; 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
- * sfk_conv_igemm_family value 4. */
-#define SFK_ABI_VERSION 14
+ * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5. */
+#define SFK_ABI_VERSION 15
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -160,7 +160,8 @@ int sfk_conv_relu_out_supported(const sfk_conv_desc* d); /* 1 if d (ignoring out
 int sfk_conv_epilogue_supported(const sfk_conv_desc* d); /* 1 if d's ep (as filled in) can run, else 0 */
 /* which kernel family sfk_conv_igemm runs for d (for tests / reports; never changes results beyond fp32 summation order):
  * 0 register-staged implicit GEMM, 1 LDS-DMA implicit GEMM, 3 the streaming pointwise kernel with the fused output transform
- * (conv_pw.hip: filter resident in LDS, no activation staging), 4 the deep-pipelined 256 x 256 tile (conv_igemm_p8.hip);
+ * (conv_pw.hip: filter resident in LDS, no activation staging), 4 the deep-pipelined 256 x 256 tile (conv_igemm_p8.hip),
+ * 5 the LDS-band 3 x 3 kernel (conv_halo.hip);
  * < 0: invalid descriptor */
 int sfk_conv_igemm_family(const sfk_conv_desc* d);
 
@@ -497,6 +498,7 @@ typedef struct {
   int32_t wgrad_p8;           /* 16:   the same structure for the MFMA-bound filter gradients (pixel axis split over workgroups, partial
                                          tiles through the workspace): on for layers where a workgroup then still runs this many
                                          64-pixel K-tiles; 0 = off                                                         */
+  int32_t igemm_halo;         /* 1:    the LDS-band kernel for the (1,3,3) stride-1 conv of slow res2 (64 -> 64, 56 x 56: conv_halo.hip)  */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

@@ -214,11 +214,11 @@ def test_conv_filter_gradient_wide_tile_bf16(hip, case):
 
 P8_CASES = [
     # cin, cout, k, s, p, (n, t, h, w)             conv_igemm_p8.hip: 256 x 256 tile, 64-channel K-tiles, staggered wave groups
-    (256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 4, 64, 64)),     # exactly 256 tiles, 3 taps x 4 K-tiles (even count)
+    (512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 4, 64, 64)),     # exactly 256 tiles, 3 taps x 8 K-tiles (even count)
     (192, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 57, 61)),     # 9 taps x 3 K-tiles = 27 (odd), ragged M, padding on every side
-    (64, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 3, 90, 94)),      # one K-tile per tap, stride 2 (strided data gradient passes), 2 co tiles
-    (512, 640, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 50, 52)),     # pointwise, 8 K-tiles, ragged co tile (640 = 2.5 tiles)
-    (192, 1024, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 9, 48, 40)),    # 4 co tiles share a pixel tile, 224-row tiles (68 x 4 vs 78 x 4)
+    (128, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 3, 90, 94)),     # two K-tiles per tap, stride 2 (strided data gradient passes), 2 co tiles
+    (1024, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 50, 52)),    # pointwise, 16 K-tiles, 3 co tiles
+    (384, 1024, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 9, 48, 40)),    # 4 co tiles share a pixel tile, 224-row tiles (68 x 4 vs 78 x 4)
     (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 64, 66)),     # 9 taps x 4 K-tiles forward AND data gradient on the tile
 ]
 
@@ -349,6 +349,68 @@ def test_conv_filter_gradient_p8_bf16(hip, case):
     hip.conv_wgrad(wp)(stream())
     torch.cuda.synchronize()
     assert float((wp.dw.cpu() - dwc).abs().max()) < 2e-5 * scale + 1e-4
+
+
+HALO_CASES = [
+    # cin = cout, (n, t, h, w)            conv_halo.hip: the (1,3,3) stride-1 conv of slow res2 out of an LDS band, filter in registers
+    (64, (2, 3, 56, 56)),       # 84 bands: one per workgroup
+    (64, (3, 8, 56, 56)),       # 336 bands: persistent workgroups take a second band (double-buffered band, slab ring across bands)
+    (64, (1, 2, 8, 56)),        # 4 bands: frames of 8 rows (first and last band of a frame adjacent)
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[f"c{c[0]}-n{c[1][0]}t{c[1][1]}" for c in HALO_CASES])
+def test_conv_halo_bf16(hip, case):
+    """conv_halo_kernel (sfk_tuning.igemm_halo): forward with BatchNorm partial sums into / out of channel slices, and the plain
+    data gradient (flipped taps, transposed filter), against the CPU restatement; two runs agree bit for bit."""
+    from video_classification_amd._lib import tuning
+    if not tuning().igemm_halo:
+        pytest.skip("the LDS-band kernel is off in this process (SFK_HALO=0)")
+    c, (n, t, h, w) = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(53 + c + n)
+    emu = EmuBackend()
+    g = ConvGeom(c, c, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    sp = fwd_pass(g, (t, h, w))
+    xc, xg = fmap_pair(n, c, t, h, w, dtype, gen, ld=c + 8, c_off=8)
+    wt = mk((c * 9 * c,), dtype, gen, scale=(9 * c) ** -0.5)
+    outs = []
+    for rep in range(2):
+        yc, yg = fmap_pair(n, c, *sp.rows, dtype, torch.Generator().manual_seed(5), ld=c + 8, c_off=8, fill=3.0)
+        pc = ConvPass(xc, yc, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt, 9, c, c)
+        pg = ConvPass(xg, yg, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), wt.to(DEV), 9, c, c)
+        assert hip.conv_family(pg) == 5
+        mt, mtc = hip.conv_igemm_mtiles(pg), emu.conv_igemm_mtiles(pc)
+        assert mt == n * t * (h // 4)
+        pc.stats = torch.zeros(mtc * c * 2)
+        pg.stats = torch.full((mt * c * 2,), float("nan"), device=DEV)
+        if rep == 0:
+            emu.conv_igemm(pc)(0)
+        hip.conv_igemm(pg)(stream())
+        torch.cuda.synchronize()
+        outs.append((yg.buf.cpu(), pg.stats.cpu()))
+        if rep == 0:
+            assert rel_err(yg.view5().float().cpu(), yc.view5().float()) < TOL[dtype]
+            assert torch.all(yg.buf.cpu().float().view(-1, c + 8)[:, :8] == 3.0)
+            sg, sc = pg.stats.cpu().view(mt, c, 2), pc.stats.view(mtc, c, 2)
+            assert torch.isfinite(sg).all() and rel_err(sg.sum(0), sc.sum(0)) < 1e-4
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and torch.equal(outs[0][1], outs[1][1])
+    # data gradient (the engine's conv_b -> conv_a hand-over: plain stores)
+    passes, _ = dgrad_passes(g, (t, h, w))
+    assert len(passes) == 1
+    dyc, dyg = fmap_pair(n, c, t, h, w, dtype, gen)
+    wtt = mk((c * 9 * c,), dtype, gen, scale=(9 * c) ** -0.5)
+    dxc, dxg = fmap_pair(n, c, t, h, w, dtype, gen, ld=c + 8, c_off=0)
+    sp_ = passes[0]
+    emu.conv_igemm(ConvPass(dyc, dxc, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wtt, 9, c, c))(0)
+    pgd = ConvPass(dyg, dxg, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wtt.to(DEV), 9, c, c)
+    assert hip.conv_family(pgd) == 5
+    hip.conv_igemm(pgd)(stream())
+    torch.cuda.synchronize()
+    assert rel_err(dxg.view5().float().cpu(), dxc.view5().float()) < TOL[dtype]
+    assert torch.equal(dxg.buf.cpu().float().view(-1, c + 8)[:, c:], dxc.buf.float().view(-1, c + 8)[:, c:])
+    # += keeps the implicit GEMM (no accumulate epilogue in the band kernel)
+    assert hip.conv_family(ConvPass(dyg, dxg, sp_.rows, sp_.gs, sp_.os, sp_.oo, list(sp_.taps), wtt.to(DEV), 9, c, c, accumulate=True)) != 5
 
 
 def test_conv_rejects_bad_descriptors(hip):

@@ -533,6 +533,70 @@ def test_metric_geometry_forward_fp32():
     assert rel_err(got, want) < FWD_TOL_F32
 
 
+def test_metric_geometry_segmented_exchange_schedule_matches_plain_step():
+    """The N > 1 backward schedule at FULL depth on the metric geometry (until now only the mini model ran it on the GPU): three
+    compute lanes + segments + buckets issued from the filter-gradient lane (dist.GradReducer's path, TrainStep._eager), with the
+    all-reduce of every bucket replaced by `g *= 2` on the collective's stand-in stream.  A bucket issued before a late write of
+    its range -- a filter gradient still running on another lane, an ordered-reduce kernel of the split sums -- would leave that
+    range un-doubled: the exchanged arena must be exactly twice the plain four-lane step's, to fp32 summation-order tolerance.
+    (RCCL itself has never run on this code: no multi-GPU node was available to any round)"""
+    from video_classification_amd import dist as sdist
+    from video_classification_amd.train import TrainStep
+
+    class Doubling(sdist.LoopbackReducer):
+        def reduce(self, ranges, producers=None, issue_on=None):
+            ranges = sdist.split_ranges(sdist.merge_ranges(ranges), self.bucket_numel)
+            self.reduced += ranges
+            cur = torch.cuda.current_stream(self.g.device)
+            issue = issue_on if issue_on is not None else cur
+            self._order_after(issue, producers or [cur])
+            ev = torch.cuda.Event()
+            ev.record(issue)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                for off, n in ranges:
+                    self.g[off:off + n].mul_(2.0)
+
+    torch.manual_seed(0)
+    om = o.canonical_slowfast_8x8(400)
+    _mild_state(om, 3)
+    m = SlowFast(arch.canonical_spec(400), dtype=torch.bfloat16, device=DEV, backend=hip_backend())
+    m.load_state_dict(om.state_dict(), strict=True)
+    del om
+    eng = m.engine
+    m.train()
+    frames = torch.randn(2, 3, 32, 224, 224, generator=torch.Generator().manual_seed(21)).to(torch.bfloat16).to(DEV)
+    labels = torch.tensor([7, 311]).to(DEV)
+    idx = pack_pathway_index(32, 4, DEV)
+    seed0 = eng.drop_seed.clone()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    TrainStep(eng, lr=0.0, use_graph=False)(frames, frames, labels, slow_t_index=idx)
+    torch.cuda.synchronize()
+    g_plain = eng.G.clone()
+    eng.drop_seed.copy_(seed0)
+    m.load_state_dict(sd0)
+    red = Doubling(eng.G, world=8, bucket_mb=32.0)
+    step = TrainStep(eng, lr=0.0, use_graph=False, reducer=red, overlap_segments=6)
+    assert step.segmented and eng.wgrad_one_lane
+    step(frames, frames, labels, slow_t_index=idx)
+    torch.cuda.synchronize()
+    g_seg = eng.G.clone()
+    cover = torch.zeros(eng.arena_numel, dtype=torch.int32)
+    for off, n in red.reduced:
+        cover[off:off + n] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1            # every arena element in exactly one bucket
+    # per layer (atomically summed pixel splits: the two runs differ in the last bits, an un-doubled range by a factor of two)
+    worst = 0.0
+    for L in eng.layers:
+        a, b_ = g_seg[L.w_off:L.w_off + L.w_numel].float(), 2.0 * g_plain[L.w_off:L.w_off + L.w_numel].float()
+        e = float((a - b_).abs().max() / (b_.abs().max() + 1e-30))
+        worst = max(worst, e)
+        assert e < 2e-2, (L.cb.conv_key, e)
+    tot = float((g_seg.float() - 2.0 * g_plain.float()).norm() / (2.0 * g_plain.float()).norm())
+    print(f"segmented exchange schedule vs plain step: worst per-layer max error {worst:.2e}, arena relative L2 {tot:.2e}")
+    assert tot < 2e-3
+
+
 class _RoundBF16(torch.autograd.Function):
     """y = bf16(x) forward, bf16(g) backward: what STORING a tensor and its gradient in bf16 does to them"""
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfk.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_p8.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_p8.hip", "stem_conv.hip", "bn.hip", "bn_tail.hip", "pool_head.hip",
+SOURCES = ["conv_igemm.hip", "conv_igemm_p8.hip", "conv_halo.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_p8.hip", "stem_conv.hip", "bn.hip", "bn_tail.hip", "pool_head.hip",
            "optim_misc.hip", "eval_input.hip"]
 
 

@@ -18,6 +18,10 @@ using namespace sfk_igemm;
 namespace sfk_igemm {
 // conv_igemm_p8.hip
 __attribute__((visibility("hidden"))) int launch_p8(const ConvK& k, int bms, dim3 grid, hipStream_t s);
+// conv_halo.hip
+__attribute__((visibility("hidden"))) bool halo_ok(const sfk_conv_desc* d);
+__attribute__((visibility("hidden"))) int halo_mtiles(const sfk_conv_desc* d);
+__attribute__((visibility("hidden"))) int launch_halo(const ConvK& k, const sfk_conv_desc* d, hipStream_t s);
 }
 
 namespace {
@@ -465,8 +469,11 @@ inline TileSel pick_tile(const sfk_conv_desc* d) {
     if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || wbytes >= 0x7FF00000ll) return {128, 128, false};
     // the deep-pipelined 256 x 256 tile (conv_igemm_p8.hip: one workgroup per CU, 64-channel K-tiles, DMAs in flight across
     // the barriers, the two wave groups of a SIMD half a phase apart) for the MFMA-bound layers: >= 8 K-tiles, a co tile that
-    // is mostly real (cout % 256 == 0 or > 512), plain / += / bitmap epilogues with 16-byte stores
-    if (sfk_tune().igemm_p8 && (d->cin % 64) == 0 && ktot >= 512 && M >= 256 * 64 && (cout % 256 == 0 || cout > 512) &&
+    // is all real (cout % 256 == 0), >= 16 K-tiles, plain / += / bitmap epilogues with 16-byte stores
+    // (measured in the step's per-layer report: with 12 K-tiles -- res4 conv_a's data gradient, K = 3 x 256 -- or a co tile that is
+    // half padding -- 640 = 2.5 tiles -- the one-tile-per-CU launch loses to the 256 x 128 ring, whose second resident workgroup
+    // overlaps one tile's epilogue with the other's main loop: 135 vs 117 us and 254 vs 211 us)
+    if (sfk_tune().igemm_p8 && (d->cin % 64) == 0 && ktot >= 1024 && M >= 256 * 64 && (cout % 256) == 0 &&
         !d->ep.scale && !d->ep.shift && !d->bnb.partials && (d->cout % 8) == 0 && (d->y.ld % 8) == 0 && (d->y.c_off % 8) == 0 &&
         (sfk_tune().igemm_wide_store || d->out_relu_bits)) {
       const int64_t nt = (cout + 255) / 256;
@@ -710,6 +717,13 @@ int launch(const sfk_conv_desc* d, hipStream_t s) {
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (halo_ok(d)) {                  // (1,3,3) stride-1 convs of slow res2 / res3: the LDS-band kernel (conv_halo.hip)
+      k.mtiles = halo_mtiles(d);
+      k.ntiles = 1;
+      return launch_halo(k, d, s);
+    }
+  }
   const TileSel ts = pick_tile(d);
   k.mtiles = (k.M + ts.bm - 1) / ts.bm;
   k.ntiles = (d->cout + ts.bn - 1) / ts.bn;
@@ -776,6 +790,7 @@ extern "C" int sfk_conv_igemm_mtiles(const sfk_conv_desc* d) {
   if (st != SFK_OK) return st;
   const int rows = pw_dgrad_rows(d);      // the streaming data-gradient kernel leaves one row per wave of a co group
   if (rows > 0) return rows;
+  if (halo_ok(d)) return halo_mtiles(d);
   const int64_t M = (int64_t)d->x.n * d->rt * d->rh * d->rw;
   const int bm = pick_tile(d).bm;
   return (int)((M + bm - 1) / bm);
@@ -800,6 +815,7 @@ extern "C" int sfk_conv_igemm_family(const sfk_conv_desc* d) {
     if (pw_dgrad_rows(d) > 0) return 3;
     if (pw_plain_route(d)) return 3;
   }
+  if (halo_ok(d)) return 5;
   const TileSel ts = pick_tile(d);
   return ts.p8 ? 4 : (ts.dma ? 1 : 0);
 }
