@@ -136,19 +136,12 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const ConvK k, const 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef HALO_STAMP
-    unsigned long long t0_, t1_, t2_, t3_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory");
-#endif
     band_begin(b + (int)gridDim.x);
     // this band has landed (every wave waited for its own pieces before the previous epilogue, or right here for the first
     // band), and every wave is through with the other buffer: the next band's pieces may overwrite it
     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef HALO_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory");
-#endif
     rd_x(0, 0);
 #pragma unroll
     for (int n = 0; n < NK; ++n) {
@@ -166,9 +159,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const ConvK k, const 
     // the next band's pieces have had 12+ k-steps: waited for here, BEFORE the epilogue's stores enter the vmcnt queue;
     // the nops cover the last MFMA's result latency for the compiler-generated readers of the accumulators (asm MFMAs carry none)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-#ifdef HALO_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory");
-#endif
     // ---- epilogue of this band.  BatchNorm partial sums FIRST, with raw barriers: the shared epilogue's __syncthreads() also
     // waits for vmcnt(0), i.e. for the band's output stores just issued -- with one persistent workgroup per CU nobody covers
     // that round trip, and it was 7,200 of a band's 13,300 cycles.  The stores go last and drain under the next band's K loop.
@@ -207,13 +197,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const ConvK k, const 
     ConvK ks = k;
     ks.stats = nullptr;
     epilogue_plain<T, EPI, 7, 2, BM, C, 2, 2, true>(ks, acc, nullptr, b, 0, wm, wn, lane, tid);
-#ifdef HALO_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3_) :: "memory");
-    if (lane == 0 && k.stats) {
-      unsigned* dbg = reinterpret_cast<unsigned*>(k.stats) + (2u << 20) + ((size_t)b * 4 + wave) * 4;
-      dbg[0] = (unsigned)(t1_ - t0_); dbg[1] = (unsigned)(t2_ - t1_); dbg[2] = (unsigned)(t3_ - t2_); dbg[3] = (unsigned)t0_;
-    }
-#endif
   };
   for (int b = b0;;) {
     band_body(0, b, b == b0);

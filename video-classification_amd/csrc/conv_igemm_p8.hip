@@ -93,9 +93,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const ConvK k) {
       const int tb = (m < k.M) ? (int)rt_ * k.gst : -(1 << 28), hb = (int)rh_ * k.gsh, wb = (int)rw_ * k.gsw;
       xbase[u][j] = (uint32_t)((((((int64_t)n_ * k.xt + (int)rt_ * k.gst) * k.xh + hb) * k.xw + wb) * k.xld + k.xoff) * 2) +
                     (uint32_t)((seg0 ^ (4 * j)) * 16);
-#ifdef P8_FAKE_L2
-      xbase[u][j] &= 0x7FFFFu;     // timing-only build: every activation read falls into a 512 KB window (L2 hits), results are garbage
-#endif
       uint32_t inv = 0;
       for (int tap = 0; tap < k.ntaps; ++tap) {
         const sfk_tap tp = k.taps[tap];
@@ -220,39 +217,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const ConvK k) {
           acc[2 * h + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][i][s], xf[j][s], acc[2 * h + i][4 * xh + j], 0, 0, 0);
         }
   };
-#ifdef P8_STAMP
-  unsigned long long t_prev;
-  unsigned cyc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) cyc[i] = 0;
-  int ph = 0;
-#define P8_STAMP_AT(slot) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    cyc[slot] += (unsigned)(t_ - t_prev); t_prev = t_; }
-#else
-#define P8_STAMP_AT(slot)
-#endif
   auto end_l = [&](const int q) __attribute__((always_inline)) {
-    P8_STAMP_AT(4 * q + 0)
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // (no lgkmcnt(0) here: hipcc waits per fragment, lgkmcnt(N) in front of the MFMA that needs it, so the first MFMAs issue
     // while the last fragments are still on their way -- +1..4 %.  Every fragment read in L(p) is consumed by an MFMA of
     // M(p), so all reads have retired before the barrier that ends M(p): the WAR argument above holds.)
-    P8_STAMP_AT(4 * q + 1)
     __builtin_amdgcn_sched_barrier(0);
-#ifndef P8_NOPRIO
     __builtin_amdgcn_s_setprio(1);
-#endif
   };
   auto end_m = [&](const int q) __attribute__((always_inline)) {
-#ifndef P8_NOPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-    P8_STAMP_AT(4 * q + 2)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    P8_STAMP_AT(4 * q + 3)
   };
   // the four phases of K-tile t (parity b = t & 1, a literal after unrolling)
   auto ktile = [&](const int b, const int t) __attribute__((always_inline)) {
@@ -271,9 +249,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const ConvK k) {
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind
-#ifdef P8_STAMP
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev) :: "memory");
-#endif
   for (int t = 0;;) {
     ktile(0, t);
     if (++t >= KT) break;
@@ -281,13 +256,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const ConvK k) {
     if (++t >= KT) break;
   }
   if (g == 0) __builtin_amdgcn_s_barrier();      // ... and group 0 meets its last one
-#ifdef P8_STAMP
-  if (lane == 0 && k.stats) {
-    unsigned* dbg = reinterpret_cast<unsigned*>(k.stats) + (2u << 20) + ((size_t)blockIdx.x * 8 + wave) * 16;   // (bench buffer: 4M floats)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dbg[i] = cyc[i];
-  }
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (out-of-range, zero-writing) look-ahead DMAs before LDS is reused
   __syncthreads();
 
