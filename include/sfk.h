@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped on EVERY change of a struct layout, a prototype or the meaning of an argument / tuning field.  include/sfk.abi holds
  * (version, hash of this header's declarations); tests/test_abi_cpu.py fails when the hash moves without the version
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
- * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256; 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
+ * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 (retired in 15); 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
  * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5. */
 #define SFK_ABI_VERSION 15
@@ -487,11 +487,8 @@ typedef struct {
                                          bit 1: 224 computed rows per tile where that fills the CUs better (M = 50,176)   */
   int32_t wgrad_target_gen;   /* 512:  ... of the register-staged filter-gradient kernels (0 = 1024); round 3: 768 -> 512,
                                          -0.15 ms per step on two boxes (fewer, longer workgroups on the side lanes)   */
-  int32_t wgrad_target_256;   /* 0:    workgroups (tiles x pixel splits, at most; 256 = one per CU) of the 256-column
-                                         filter-gradient tile; 0 = never use that tile.  Off by default: alone on the chip it is
-                                         25..29 % faster on res4 (684 vs 532 TFLOP/s), but a workgroup owns its whole CU (96 KB of
-                                         LDS, 8 x 256 VGPRs), so beside the trunk's kernels the STEP loses 1.4 %             */
-  int32_t wgrad_min_stages_256; /* 48: ... which runs only where a workgroup then still has this many 32-pixel stages        */
+  int32_t wgrad_target_256;   /* retired (ignored): the round-3 256-column ring tile; conv_wgrad_p8.hip serves those layers (wgrad_p8) */
+  int32_t wgrad_min_stages_256; /* retired (ignored)                                                                          */
   int32_t igemm_p8;           /* 1:    bit 0: the deep-pipelined 256 x 256 conv tile (one workgroup per CU, 64-channel K-tiles, LDS-DMA
                                          in flight across the barriers, wave groups half a phase apart) for the MFMA-bound
                                          layers; bit 1: 224 computed rows per tile where that needs fewer row-generations   */

@@ -15,6 +15,7 @@ SFK_PER_LAYER=gpurun_out/per_layer.json timeout -k 10 600 python bench.py --gpus
 rc=$?; echo "per-layer exit $rc"
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 python tools/per_layer_report.py gpurun_out/per_layer.json gpurun_out/per_layer.txt && head -n 22 gpurun_out/per_layer.txt
+python tools/lane_timeline.py gpurun_out/per_layer.json.lanes gpurun_out/per_layer.json 300 > gpurun_out/lane_timeline.txt 2>&1; head -n 6 gpurun_out/lane_timeline.txt
 rm -rf gpurun_out/prof/*
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline > gpurun_out/bench_traced.log 2>&1
 rc=$?; echo "rocprof exit $rc"; tail -n 1 gpurun_out/bench_traced.log | cut -c1-300

@@ -12,9 +12,6 @@ for f in $FILES; do
   grep -E "^(FAILED|ERROR)|worst" gpurun_out/$name.log | head -40 | tee -a gpurun_out/tests_summary.log
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/tests_summary.log; exit $rc; fi
 done
-# opt-in kernels: the 256-column filter-gradient tile (tuning knob off by default)
-SFK_WGT256=256 timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -p no:cacheprovider -k "wide_tile or filter_gradient" > gpurun_out/test_gpu_kernels_wgt256.log 2>&1
-echo "test_gpu_kernels (SFK_WGT256=256) exit $?: $(tail -n 1 gpurun_out/test_gpu_kernels_wgt256.log)" | tee -a gpurun_out/tests_summary.log
 # the deep-pipelined tiles with every case eligible: 224-row conv tiles (SFK_P8=3), filter-gradient tile from 2 K-tiles per workgroup (SFK_WGP8=2)
 SFK_P8=3 SFK_WGP8=2 timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -p no:cacheprovider -k "p8 or conv_forward or data_gradient or filter_gradient" > gpurun_out/test_gpu_kernels_p8.log 2>&1
 echo "test_gpu_kernels (SFK_P8=3 SFK_WGP8=2) exit $?: $(tail -n 1 gpurun_out/test_gpu_kernels_p8.log)" | tee -a gpurun_out/tests_summary.log

@@ -207,7 +207,7 @@ TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK
               "SFK_WG_WIDECO": "wgrad_wide_co", "SFK_BN_PARTS": "bn_parts", "SFK_NT_APPLY_MB": "nt_apply_mb",
               "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks",
               "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_WGTG": "wgrad_target_gen",
-              "SFK_WGT256": "wgrad_target_256", "SFK_WGMIN256": "wgrad_min_stages_256", "SFK_P8": "igemm_p8",
+              "SFK_P8": "igemm_p8",
               "SFK_WGP8": "wgrad_p8", "SFK_HALO": "igemm_halo"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -275,7 +275,7 @@ __device__ __forceinline__ void wg_swap16f(float& a, float& b) {
 // on the wire; with one or two workgroups per CU that -- not the MFMAs -- sets the rate of the HBM-bound layers: by Little's
 // law 192 workgroups x 32 KB at ~2 us are 3 TB/s, which is what the 3-slot ring measured on slow res2 / res3 (3.0 .. 3.9).
 template <int TCO, int NW, bool DG = false, int TCI = 128, int NS = 3>
-__global__ __launch_bounds__(64 * NW, (TCI == 256 ? 2 : (NW == 8 ? 4 : 3))) void conv_wgrad_dma_kernel(const WgradK k) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 3)) void conv_wgrad_dma_kernel(const WgradK k) {
   constexpr int R = MK;
   constexpr int LO = TCO * 2, LI = TCI * 2;                 // tile row bytes
   constexpr int SO = LO / 16, SI = LI / 16;                 // 16-byte slots per row
@@ -553,8 +553,7 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   // pixel splits: one resident generation of workgroups (2 x 256 CUs for the 8-wave tile, 3 x 256 for the 4-wave one).
   // Every split adds a full copy of the tile to the fp32 atomic traffic (~1.3 TB/s chip-wide), so do not over-split.
   const int target8 = sfk_tune().wgrad_target_8w, target4 = sfk_tune().wgrad_target_4w;   // resident-block targets
-  int splits = ((TCI == 256 ? sfk_tune().wgrad_target_256 : (NW == 8 ? target8 : target4)) + base - 1) / base;
-  if (TCI == 256) splits = sfk_tune().wgrad_target_256 / base;      // never more workgroups than the target: one per CU
+  int splits = ((NW == 8 ? target8 : target4) + base - 1) / base;
   const int max_splits = (k.nchunks + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -565,28 +564,10 @@ int launch_dma(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) 
   const int64_t need = (int64_t)splits * base * NW * (4 * FI) * 64 * 16;
   if (dry) { *dry = need; return SFK_OK; }
   if (k.ws && need > d->workspace_bytes) k.ws = nullptr;
-  if (TCI == 256 && !k.ws) return SFK_ERR_UNSUPPORTED;      // (the caller routes to the 128-column tile instead)
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<TCO, NW, DG, TCI, NS>), dim3((unsigned)(base * splits)), dim3(64 * NW), 0, s, k);
   SFK_CHECK_LAUNCH();
   if (k.ws) return launch_reduce<NW, TCO / 64, 4, FI>(k, splits, s);
   return SFK_OK;
-}
-
-// The 256-column tile (conv_wgrad_dma_kernel<., 8, false, 256>): MFMA-bound layers whose pixel axis is long enough that one
-// workgroup per CU still runs >= wgrad_min_stages_256 stages.  0: not a layer for it; else the tile's co extent (256).
-int wide_tile_co(const sfk_wgrad_desc* d, int M) {
-  if (!sfk_tune().wgrad_target_256 || d->x.dtype != SFK_BF16) return 0;
-  const int cols = d->ntaps * d->cin;
-  // (a 128 x 256 variant -- 4 waves of 64 x 128, two workgroups per CU -- was measured on slow res3's 3 x 3 layers: 162 vs 157 us
-  // for the 128-column tile, so layers with fewer than 256 output channels keep that one)
-  if (cols < 512 || d->cout < 256) return 0;
-  if (sfk_fmap_bytes(&d->x) >= 0x7FF00000ll || sfk_fmap_bytes(&d->dy) >= 0x7FF00000ll) return 0;
-  const int tco = 256;
-  const int base = ((d->cout + tco - 1) / tco) * ((cols + 255) / 256);
-  const int splits = sfk_tune().wgrad_target_256 / base;
-  if (splits < 1) return 0;
-  const int nchunks = (M + MK - 1) / MK;
-  return nchunks / splits >= sfk_tune().wgrad_min_stages_256 ? tco : 0;
 }
 
 // the fused data gradient rides on the 256 x 128 LDS-DMA tile with taps x cin = 64 (its second column half is idle)
@@ -669,11 +650,6 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
       const int r = launch_wgrad_p8(k, d, s, dry);
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
-    const int wt = (!d->dg_w && (dry || k.ws)) ? wide_tile_co(d, k.M) : 0;
-    if (wt) {       // (no workspace / too small a one: SFK_ERR_UNSUPPORTED, and the 128-column tile below runs with atomics)
-      const int r = launch_dma<256, 8, false, 256>(k, d, s, dry);
-      if (r != SFK_ERR_UNSUPPORTED) return r;
-    }
   }
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
@@ -724,7 +700,7 @@ extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
 extern "C" int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d) {
   if (!d || validate(d) != SFK_OK || d->dg_w) return 0;
   const int M = (int)sfk_fmap_pixels(&d->dy);
-  return (wgrad_p8_ok(d, M) || wide_tile_co(d, M)) ? 1 : 0;
+  return wgrad_p8_ok(d, M) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d) {
