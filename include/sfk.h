@@ -241,7 +241,8 @@ int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, float* dw, sf
  * workspace: NULL, or [SFK_BN_FOLD_ROWS][c][2] floats of scratch: with it, more than 4096 rows (the stems of the metric
  * geometry leave 50,176) are first folded down by a grid of workgroups; up to that a 256-thread block per channel pair
  * folds the rows in the finalize launch itself.  Either way the sums are accumulated in double in a fixed order
- * (deterministic).  c must be even (SFK_ERR_UNSUPPORTED otherwise; feature maps have c % 4 == 0). */
+ * (deterministic).  c must be even (SFK_ERR_UNSUPPORTED otherwise; feature maps have c % 4 == 0); `partials` and `workspace` must
+ * be 16-byte aligned (SFK_ERR_INVALID otherwise: the rows are read as float4), likewise in sfk_bn_bwd_finalize. */
 int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c, int64_t count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
@@ -337,7 +338,8 @@ int sfk_bn_tail_bwd(const float* r, const float* dz_partials, int32_t nparts, co
  * streaming pass instead of two MFMA tiles that are all epilogue at 8 .. 16 output channels).  fp32 accumulation, one
  * rounding; all three maps share the pixel grid, w1 [y.c][x1.c], w2 [y.c][x2.c] row-major in the maps' dtype, bias fp32 or NULL.
  * sfk_conv_pw_dual_supported: 1 for the channel counts the kernel is built for ((x1.c, x2.c, y.c) = (32, 8, 8), (64, 16, 16)),
- * bf16, 16-byte aligned pixel records; everything else keeps the two sfk_conv_igemm passes. */
+ * bf16, 16-byte aligned pixel records; everything else keeps the two sfk_conv_igemm passes.  w1 / w2 must be 4-byte aligned
+ * (SFK_ERR_INVALID otherwise: they are read as packed bf16 pairs). */
 int sfk_conv_pw_dual_supported(const sfk_fmap* x1, const sfk_fmap* x2, const sfk_fmap* y);
 int sfk_conv_pw_dual(const sfk_fmap* x1, const void* w1, const sfk_fmap* x2, const void* w2, const float* bias,
                      const sfk_fmap* y, sfk_stream_t stream);

@@ -199,3 +199,26 @@ def test_streaming_pointwise_routes_refuse_maps_beyond_32_bit_offsets(lib):
     d.y.ld -= d.y.ld % 8
     assert d.y.ld * 2 * n * t * h * w >= (1 << 32) - 64
     assert lib.sfk_conv_igemm_family(ctypes.byref(d)) in (0, 1)        # implicit GEMM, not the 32-bit streaming route
+
+
+def test_misaligned_vector_operands_are_rejected_on_the_host(lib):
+    """sfk_conv_pw_dual reads its filters as packed bf16 pairs, the BatchNorm finalize launches read partial rows as float4:
+    an odd pointer must come back as SFK_ERR_INVALID from the host check, not as a misaligned-access fault on the device.
+    Nothing is launched (the checks come before the first HIP call), the pointers are never dereferenced."""
+    from video_classification_amd import _lib
+    maps = []
+    for c in (32, 8, 8):
+        m = _lib._FMap()
+        m.ptr, m.dtype, m.n, m.t, m.h, m.w, m.c, m.ld, m.c_off = 0x10000, 1, 1, 2, 4, 4, c, c, 0
+        maps.append(m)
+    x1, x2, y = maps
+    assert lib.sfk_conv_pw_dual_supported(ctypes.byref(x1), ctypes.byref(x2), ctypes.byref(y)) == 1
+    for w1, w2 in ((0x20002, 0x30000), (0x20000, 0x30002), (0x20001, 0x30000)):
+        assert lib.sfk_conv_pw_dual(ctypes.byref(x1), w1, ctypes.byref(x2), w2, None, ctypes.byref(y), None) == -1
+    PF = ctypes.POINTER(ctypes.c_float)
+    f = lambda a: ctypes.cast(a, PF)
+    ok = f(0x40000)
+    for partials, ws in ((0x50008, None), (0x50000, 0x60004)):
+        assert lib.sfk_bn_finalize(f(partials), 4, 8, 100, ok, ok, 1e-5, 0.1, None, None, None, ok, ok, ok, ok,
+                                   f(ws) if ws else None, None) == -1
+        assert lib.sfk_bn_bwd_finalize(f(partials), 4, 8, 100, ok, ok, ok, ok, ok, f(ws) if ws else None, None) == -1

@@ -200,3 +200,83 @@ def test_eval_with_fewer_videos_than_ranks_does_not_hang(tmp_path):
     assert a["sv"] == b["sv"] == [2] and a["acc"] == b["acc"]
     assert a["ps"].shape == b["ps"].shape == (2, 5) and abs(a["ps"] - b["ps"]).max() == 0
     assert (a["t"] == b["t"]).all()
+
+
+class _FakeStream:
+    def __init__(self, name, log):
+        self.name, self.log = name, log
+
+    def wait_event(self, ev):
+        self.log.append(("wait", self.name, ev.recorded_on))
+
+
+def test_grad_reducer_async_handles_and_lane_order(monkeypatch):
+    """The CUDA branch of GradReducer without a GPU: torch.cuda's streams / events and dist.all_reduce are stand-ins that log.
+    reduce() must make the issue lane wait for EVERY other producer before the first bucket is enqueued, enqueue each bucket
+    with async_op=True from the issue lane, and finish() must wait on every Work handle exactly once and then forget them."""
+    import contextlib
+    from video_classification_amd import dist as sdist
+    log = []
+    cur = _FakeStream("cur", log)
+    active = [cur]
+
+    class Ev:
+        def record(self, s):
+            self.recorded_on = s.name
+
+    class Work:
+        def __init__(self, n):
+            self.n, self.waits = n, 0
+
+        def wait(self):
+            self.waits += 1
+            log.append(("work.wait", self.n))
+
+    works = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        log.append(("all_reduce", active[-1].name, int(t.numel()), bool(async_op)))
+        w = Work(int(t.numel()))
+        works.append(w)
+        return w
+
+    @contextlib.contextmanager
+    def fake_stream_ctx(s):
+        active.append(s)
+        try:
+            yield
+        finally:
+            active.pop()
+
+    monkeypatch.setattr(sdist.torch.cuda, "Event", Ev)
+    monkeypatch.setattr(sdist.torch.cuda, "current_stream", lambda dev=None: cur)
+    monkeypatch.setattr(sdist.torch.cuda, "stream", fake_stream_ctx)
+    monkeypatch.setattr(sdist.dist, "all_reduce", fake_all_reduce)
+    g = torch.zeros(1000)
+    red = sdist.GradReducer(g, bucket_mb=400 * 4 / (1 << 20))           # 400-element buckets
+    red.world, red.cuda = 2, True
+    red.begin()
+    trunk, fast, wg = (_FakeStream(n, log) for n in ("trunk", "fast", "wg"))
+    red.reduce([(0, 300), (300, 500)], producers=[trunk, fast, wg], issue_on=wg)      # merged to (0, 800): two buckets
+    first_ar = next(i for i, e in enumerate(log) if e[0] == "all_reduce")
+    assert sorted(log[:first_ar]) == [("wait", "wg", "fast"), ("wait", "wg", "trunk")]   # not on itself; before any bucket
+    assert log[first_ar:] == [("all_reduce", "wg", 400, True), ("all_reduce", "wg", 400, True)]
+    assert red.reduced == [(0, 400), (400, 400)] and len(red.handles) == 2
+    red.reduce([(800, 200)])                                            # defaults: produced and issued on the current stream
+    assert log[-1] == ("all_reduce", "cur", 200, True) and not [e for e in log[first_ar + 2:] if e[0] == "wait"]
+    assert all(w.waits == 0 for w in works)                             # nobody waits for a collective before finish()
+    assert red.finish() == 0.5
+    assert [w.waits for w in works] == [1, 1, 1] and red.handles == []
+    assert red.finish() == 0.5 and [w.waits for w in works] == [1, 1, 1]      # a second finish() has nothing left to wait on
+
+
+def test_gather_eval_skips_the_placeholder_rows_of_an_empty_shard(monkeypatch):
+    """the res2d network scores 1000 classes (reference train.py:64-76) while an empty shard's zero-row placeholder is
+    NUM_CLASS wide: the gather must not concatenate it (torch.cat refuses (0, 5) next to (n, 1000))."""
+    from video_classification_amd import dist as sdist
+    from video_classification_amd.train import Trainer
+    full = (torch.arange(3000, dtype=torch.float32).reshape(3, 1000), torch.tensor([4, 4, 7]), [2, 1])
+    empty = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), [])
+    monkeypatch.setattr(sdist, "gather_objects", lambda obj: [full, (empty[0], empty[1], [0])])
+    lg, lb, sv = Trainer._gather_eval(None, empty[0], empty[1], [0], (1, 2, 3))
+    assert sv == [2, 0, 1] and lg.shape == (3, 1000) and torch.equal(lg, full[0]) and lb.tolist() == [4, 4, 7]

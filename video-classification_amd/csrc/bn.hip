@@ -646,6 +646,7 @@ extern "C" int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c,
     return SFK_ERR_INVALID;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SFK_ERR_INVALID;
   if (c & 1) return SFK_ERR_UNSUPPORTED;           // a block folds a channel PAIR (16-byte loads); maps have c % 4 == 0
+  if ((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) return SFK_ERR_INVALID;   // rows are read as float4
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c / 2), dim3(256), 0, s, partials,
@@ -808,6 +809,7 @@ extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_
                                    float* workspace, sfk_stream_t stream) {
   if (!partials || nparts <= 0 || c <= 0 || count <= 0 || !gamma || !invstd || !coef) return SFK_ERR_INVALID;
   if (c & 1) return SFK_ERR_UNSUPPORTED;
+  if ((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) return SFK_ERR_INVALID;   // rows are read as float4
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 2), dim3(256), 0, s,

@@ -428,6 +428,7 @@ extern "C" int sfk_conv_pw_dual(const sfk_fmap* x1, const void* w1, const sfk_fm
                                 const sfk_fmap* y, sfk_stream_t stream) {
   if (!x1 || !x2 || !y || !w1 || !w2 || !sfk_fmap_ok(x1) || !sfk_fmap_ok(x2) || !sfk_fmap_ok(y)) return SFK_ERR_INVALID;
   if (!sfk_conv_pw_dual_supported(x1, x2, y)) return SFK_ERR_UNSUPPORTED;
+  if ((((uintptr_t)w1) | ((uintptr_t)w2)) & 3) return SFK_ERR_INVALID;        // the filters are read as packed bf16 pairs
   const int64_t px = sfk_fmap_pixels(y);
   int64_t blocks = (px + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -486,6 +486,8 @@ class Trainer:
         else:
             # a rank whose shard holds no video (fewer test videos than ranks): zero rows, so that it still takes part in
             # the gather below instead of raising while the other ranks wait in all_gather_object
+            # (the width is a placeholder: the res2d network scores 1000 classes, reference train.py:64-76; _gather_eval never
+            # concatenates a zero-row part)
             logits = torch.zeros(0, int(self.cfg.CHALEARN.NUM_CLASS), dtype=torch.float32, device=self.device)
             labels = torch.zeros(0, dtype=torch.int64, device=self.device)
         shard = getattr(loader, "sfk_shard", None)
@@ -522,10 +524,13 @@ class Trainer:
         for v in range(total):
             r, j = v % world, v // world
             lg, lb, s_ = parts[r]
-            rows_l.append(lg[offs[r][j]:offs[r][j + 1]])
-            rows_t.append(lb[offs[r][j]:offs[r][j + 1]])
+            if offs[r][j + 1] > offs[r][j]:         # zero-row parts (an empty shard's placeholder width) stay out of the cat
+                rows_l.append(lg[offs[r][j]:offs[r][j + 1]])
+                rows_t.append(lb[offs[r][j]:offs[r][j + 1]])
             sv_all.append(s_[j])
         dev = logits.device
+        if not rows_l:
+            return logits, labels, sv_all
         return (torch.cat(rows_l, 0).to(dev).contiguous(), torch.cat(rows_t, 0).to(dev).contiguous(), sv_all)
 
 
