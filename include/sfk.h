@@ -39,8 +39,8 @@ extern "C" {
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 (retired in 15); 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
- * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5. */
-#define SFK_ABI_VERSION 15
+ * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band. */
+#define SFK_ABI_VERSION 16
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -498,6 +498,8 @@ typedef struct {
                                          tiles through the workspace): on for layers where a workgroup then still runs this many
                                          64-pixel K-tiles; 0 = off                                                         */
   int32_t igemm_halo;         /* 1:    the LDS-band kernel for the (1,3,3) stride-1 conv of slow res2 (64 -> 64, 56 x 56: conv_halo.hip)  */
+  int32_t wgrad_band;         /* 1:    the LDS-band filter-gradient kernel for the same layer (whole 64 x 576 dW in one workgroup's
+                                         accumulators, partials through the workspace: conv_wgrad_band.hip)                  */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

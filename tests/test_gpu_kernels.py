@@ -297,6 +297,56 @@ def test_conv_filter_gradient_p8_bf16(hip, case):
     assert float((wp.dw.cpu() - dwc).abs().max()) < 2e-5 * scale + 1e-4
 
 
+BAND_WGRAD_CASES = [
+    # (n, t, h, w)          conv_wgrad_band.hip: the 64 -> 64 (1,3,3) filter gradient out of LDS bands, whole dW in one workgroup's accumulators
+    (2, 4, 56, 56),         # 112 bands, one per workgroup: the K-parity-1 waves run the odd K-steps only
+    (3, 8, 56, 56),         # 336 bands on 256 workgroups: one or two bands each (both buffers)
+    (5, 8, 8, 56),          # frames of 8 rows: every band is the first or the last of its frame
+    (9, 8, 56, 56),         # 1008 bands: three or four per workgroup, the buffers alternate
+]
+
+
+@pytest.mark.parametrize("case", BAND_WGRAD_CASES, ids=[f"n{c[0]}t{c[1]}h{c[2]}" for c in BAND_WGRAD_CASES])
+def test_conv_filter_gradient_band_bf16(hip, case):
+    """conv_wgrad_band_kernel (sfk_tuning.wgrad_band): against the CPU restatement, out of / into channel slices, into a dW that
+    already holds values; two runs agree bit for bit (ordered sum of the workgroups' partials); without a workspace the call
+    still gives the same gradient (implicit-GEMM kernels)."""
+    from video_classification_amd._lib import tuning
+    if not tuning().wgrad_band:
+        pytest.skip("the LDS-band filter-gradient kernel is off in this process (SFK_WGBAND=0)")
+    n, t, h, w = case
+    cin = cout = 64
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(67 + n + h)
+    emu = EmuBackend()
+    g = ConvGeom(cin, cout, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    xc, xg = fmap_pair(n, cin, t, h, w, dtype, gen, ld=cin + 8, c_off=8)
+    dyc, dyg = fmap_pair(n, cout, t, h, w, dtype, gen, ld=cout + 16, c_off=8)
+    base = torch.randn(cout * g.wtaps * cin, generator=gen)
+    dwc = base.clone()
+    emu.conv_wgrad(WgradPass(xc, dyc, g.s, list(wgrad_taps(g)), dwc, g.wtaps, cin, cout))(0)
+    wp = WgradPass(xg, dyg, g.s, list(wgrad_taps(g)), None, g.wtaps, cin, cout)
+    wp.dw = base.clone().to(DEV)
+    assert hip.conv_wgrad_wants_workspace(wp)
+    need = hip.conv_wgrad_workspace_bytes(wp)
+    assert need == min(256, n * t * (h // 4)) * 144 * 1024           # one 64 x 576 fp32 partial per workgroup
+    outs = []
+    for _ in range(2):
+        wp.dw = base.clone().to(DEV)
+        wp.workspace = torch.full((need // 4 + 4,), float("nan"), device=DEV)
+        hip.conv_wgrad(wp)(stream())
+        torch.cuda.synchronize()
+        outs.append(wp.dw.cpu())
+    scale = float((dwc - base).abs().max())
+    assert float((outs[0] - dwc).abs().max()) < 2e-5 * scale + 1e-4, (float((outs[0] - dwc).abs().max()), scale)
+    assert torch.equal(outs[0], outs[1])
+    wp.dw = base.clone().to(DEV)                                   # no workspace: the implicit-GEMM kernels with atomics
+    wp.workspace = None
+    hip.conv_wgrad(wp)(stream())
+    torch.cuda.synchronize()
+    assert float((wp.dw.cpu() - dwc).abs().max()) < 2e-5 * scale + 1e-4
+
+
 HALO_CASES = [
     # cin = cout, (n, t, h, w)            conv_halo.hip: the (1,3,3) stride-1 conv of slow res2 out of an LDS band, filter in registers
     (64, (2, 3, 56, 56)),       # 84 bands: one per workgroup

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfk.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_p8.hip", "conv_halo.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_p8.hip", "stem_conv.hip", "bn.hip", "bn_tail.hip", "pool_head.hip",
+SOURCES = ["conv_igemm.hip", "conv_igemm_p8.hip", "conv_halo.hip", "conv_pw.hip", "conv_wgrad.hip", "conv_wgrad_p8.hip", "conv_wgrad_band.hip", "stem_conv.hip", "bn.hip", "bn_tail.hip", "pool_head.hip",
            "optim_misc.hip", "eval_input.hip"]
 
 
@@ -21,7 +21,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         hipcc = "hipcc"
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(CSRC, "sfk_common.h"), os.path.join(CSRC, "conv_igemm_epi.h"), os.path.join(CSRC, "conv_wgrad_common.h"), os.path.join(ROOT, "include", "sfk.h")]
+    deps = [os.path.join(CSRC, "sfk_common.h"), os.path.join(CSRC, "conv_igemm_epi.h"), os.path.join(CSRC, "conv_wgrad_common.h"), os.path.join(CSRC, "conv_wgrad_band_acc.inc"), os.path.join(ROOT, "include", "sfk.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     flags += os.environ.get("SFK_EXTRA_FLAGS", "").split()          # experiment builds (tools/), with SFK_LIB_OUT
 

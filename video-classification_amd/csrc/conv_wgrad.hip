@@ -18,6 +18,9 @@ namespace sfk_wgrad {
 // conv_wgrad_p8.hip: the deep-pipelined 256 x 256 tile of the MFMA-bound layers (dry != NULL: workspace bytes only)
 __attribute__((visibility("hidden"))) int launch_wgrad_p8(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry);
 __attribute__((visibility("hidden"))) bool wgrad_p8_ok(const sfk_wgrad_desc* d, int M);
+// conv_wgrad_band.hip: the LDS-band kernel of the (1,3,3) 64 -> 64 layer over 56 x 56 frames; workspace only
+__attribute__((visibility("hidden"))) int launch_wgrad_band(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry);
+__attribute__((visibility("hidden"))) bool wgrad_band_ok(const sfk_wgrad_desc* d);
 }
 
 namespace {
@@ -650,6 +653,10 @@ int launch(const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry = nullptr) {
       const int r = launch_wgrad_p8(k, d, s, dry);
       if (r != SFK_ERR_UNSUPPORTED) return r;
     }
+    if ((dry || k.ws) && wgrad_band_ok(d)) {
+      const int r = launch_wgrad_band(k, d, s, dry);
+      if (r != SFK_ERR_UNSUPPORTED) return r;
+    }
   }
   if (sizeof(T) == 2 && cols >= 128 && d->cout >= 128 && k.xbytes < 0x7FF00000u && k.dbytes < 0x7FF00000u) {
     // wide layers: LDS-DMA ring; 256 output channels per tile once that still leaves enough workgroups
@@ -700,7 +707,7 @@ extern "C" int64_t sfk_conv_wgrad_workspace_bytes(const sfk_wgrad_desc* d) {
 extern "C" int sfk_conv_wgrad_wants_workspace(const sfk_wgrad_desc* d) {
   if (!d || validate(d) != SFK_OK || d->dg_w) return 0;
   const int M = (int)sfk_fmap_pixels(&d->dy);
-  return wgrad_p8_ok(d, M) ? 1 : 0;
+  return (wgrad_p8_ok(d, M) || wgrad_band_ok(d)) ? 1 : 0;
 }
 
 extern "C" int sfk_conv_wgrad_dg_supported(const sfk_wgrad_desc* d) {
