@@ -498,8 +498,9 @@ typedef struct {
                                          tiles through the workspace): on for layers where a workgroup then still runs this many
                                          64-pixel K-tiles; 0 = off                                                         */
   int32_t igemm_halo;         /* 1:    the LDS-band kernel for the (1,3,3) stride-1 conv of slow res2 (64 -> 64, 56 x 56: conv_halo.hip)  */
-  int32_t wgrad_band;         /* 1:    the LDS-band filter-gradient kernel for the same layer (whole 64 x 576 dW in one workgroup's
-                                         accumulators, partials through the workspace: conv_wgrad_band.hip)                  */
+  int32_t wgrad_band;         /* 3:    the LDS-band filter-gradient kernel (whole dW in the workgroups' accumulators, partials through the
+                                         workspace: conv_wgrad_band.hip): bit 0: 64 -> 64 (1,3,3) over 56 x 56 frames (slow res2 conv_b);
+                                         bit 1: 128 -> 128 over 28 x 28 (slow res3 conv_b)                                  */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

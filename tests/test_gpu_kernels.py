@@ -298,15 +298,18 @@ def test_conv_filter_gradient_p8_bf16(hip, case):
 
 
 BAND_WGRAD_CASES = [
-    # (n, t, h, w)          conv_wgrad_band.hip: the 64 -> 64 (1,3,3) filter gradient out of LDS bands, whole dW in one workgroup's accumulators
-    (2, 4, 56, 56),         # 112 bands, one per workgroup: the K-parity-1 waves run the odd K-steps only
-    (3, 8, 56, 56),         # 336 bands on 256 workgroups: one or two bands each (both buffers)
-    (5, 8, 8, 56),          # frames of 8 rows: every band is the first or the last of its frame
-    (9, 8, 56, 56),         # 1008 bands: three or four per workgroup, the buffers alternate
+    # c, (n, t, h, w)       conv_wgrad_band.hip: the (1,3,3) filter gradient out of LDS bands, whole dW in the workgroups' accumulators
+    (64, (2, 4, 56, 56)),   # 112 bands, one per workgroup: the K-parity-1 waves run the odd K-steps only
+    (64, (3, 8, 56, 56)),   # 336 bands on 256 workgroups: one or two bands each (both buffers)
+    (64, (5, 8, 8, 56)),    # frames of 8 rows: every band is the first or the last of its frame
+    (64, (9, 8, 56, 56)),   # 1008 bands: three or four per workgroup, the buffers alternate
+    (128, (2, 5, 28, 28)),  # 70 bands x 2 input-channel halves on 140 workgroups (half K-step at the end of every band)
+    (128, (9, 8, 28, 28)),  # 1008 units: three or four per workgroup
+    (128, (10, 4, 8, 28)),  # frames of 8 rows
 ]
 
 
-@pytest.mark.parametrize("case", BAND_WGRAD_CASES, ids=[f"n{c[0]}t{c[1]}h{c[2]}" for c in BAND_WGRAD_CASES])
+@pytest.mark.parametrize("case", BAND_WGRAD_CASES, ids=[f"c{c[0]}-n{c[1][0]}t{c[1][1]}h{c[1][2]}" for c in BAND_WGRAD_CASES])
 def test_conv_filter_gradient_band_bf16(hip, case):
     """conv_wgrad_band_kernel (sfk_tuning.wgrad_band): against the CPU restatement, out of / into channel slices, into a dW that
     already holds values; two runs agree bit for bit (ordered sum of the workgroups' partials); without a workspace the call
@@ -314,8 +317,10 @@ def test_conv_filter_gradient_band_bf16(hip, case):
     from video_classification_amd._lib import tuning
     if not tuning().wgrad_band:
         pytest.skip("the LDS-band filter-gradient kernel is off in this process (SFK_WGBAND=0)")
-    n, t, h, w = case
-    cin = cout = 64
+    cin, (n, t, h, w) = case
+    cout = cin
+    if not (tuning().wgrad_band & (1 if cin == 64 else 2)):
+        pytest.skip("this width of the LDS-band filter-gradient kernel is off in this process (SFK_WGBAND)")
     dtype = torch.bfloat16
     gen = torch.Generator().manual_seed(67 + n + h)
     emu = EmuBackend()
@@ -329,7 +334,7 @@ def test_conv_filter_gradient_band_bf16(hip, case):
     wp.dw = base.clone().to(DEV)
     assert hip.conv_wgrad_wants_workspace(wp)
     need = hip.conv_wgrad_workspace_bytes(wp)
-    assert need == min(256, n * t * (h // 4)) * 144 * 1024           # one 64 x 576 fp32 partial per workgroup
+    assert need == min(256, n * t * (h // 4) * (cin // 64)) * (cout // 64) * 144 * 1024    # one (cout x 576) fp32 partial per workgroup
     outs = []
     for _ in range(2):
         wp.dw = base.clone().to(DEV)

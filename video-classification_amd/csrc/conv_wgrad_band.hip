@@ -25,6 +25,10 @@
 // goes to the caller's workspace, band_reduce_kernel adds the workgroups' partials in a fixed order (deterministic).
 #include "conv_wgrad_common.h"
 
+#ifndef SFK_BAND_EXP
+#define SFK_BAND_EXP 0      // timing experiments (tools/gpu_wband.sh; results are wrong): 1 no MFMAs, 2 no per-band DMAs, 3 no fragment reads
+#endif
+
 namespace sfk_wgrad {
 
 typedef __attribute__((address_space(3))) void lds_void_wb_t;
@@ -87,10 +91,21 @@ __device__ __forceinline__ void band_tap_mfma(f32x4 (&acc8)[4], const bf16x8 (&f
 }
 
 // one K-step S of the band in the buffer the address registers point into: 8 + 18 transposed reads, 36 MFMAs
-template <class Cfg, int S>
-__device__ __forceinline__ void band_kstep(f32x4 (&acc8)[4], const uint32_t abase, const uint32_t xb0, const uint32_t xb1) {
+// `dma()` issues this K-step's share of the NEXT band's LDS-DMAs behind the fragment reads (under their latency); `hi`: the
+// wave's MFMA priority (2 for kg = 0, 1 for kg = 1: with equal priorities the two waves of a SIMD interleave their MFMA blocks,
+// finish together and then both sit in their reads with the matrix pipe idle)
+template <class Cfg, int S, class Dma>
+__device__ __forceinline__ void band_kstep(f32x4 (&acc8)[4], const uint32_t abase, const uint32_t xb0, const uint32_t xb1, const bool hi,
+                                           Dma&& dma) {
   constexpr bool HALF = Cfg::HALF_LAST && S == Cfg::NS - 1;
   bf16x4 af[4][2], bf[9][2];
+#if SFK_BAND_EXP == 3
+#pragma unroll
+  for (int c = 0; c < 4; ++c) af[c][0] = af[c][1] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) bf[t][0] = bf[t][1] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0]) : "v"(abase), "v"(xb0), "v"(xb1));
+#else
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     switch (c) {      // (the immediates must be literals)
@@ -106,6 +121,8 @@ __device__ __forceinline__ void band_kstep(f32x4 (&acc8)[4], const uint32_t abas
   SFK_BAND_TAP(0) SFK_BAND_TAP(1) SFK_BAND_TAP(2) SFK_BAND_TAP(3) SFK_BAND_TAP(4)
   SFK_BAND_TAP(5) SFK_BAND_TAP(6) SFK_BAND_TAP(7) SFK_BAND_TAP(8)
 #undef SFK_BAND_TAP
+#endif
+  dma();
   if (HALF) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) af[c][1] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
@@ -114,12 +131,18 @@ __device__ __forceinline__ void band_kstep(f32x4 (&acc8)[4], const uint32_t abas
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the asm reads have returned (hipcc does not track them)
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
+  if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
   // asm MFMAs on fixed AGPRs (conv_wgrad_band_acc.inc): from the builtin, and from "+a" operands, hipcc kept the 144 loop-carried
   // accumulators in VGPRs, copied them per K-step and spilled ~200 registers
   bf16x8 fa[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) fa[c] = frag8(af[c][0], af[c][1]);
+#if SFK_BAND_EXP == 1
+#pragma unroll
+  for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(fa[c]));
+#pragma unroll
+  for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(bf[t][0]), "v"(bf[t][1]));
+#else
   // the ninth tap FIRST: its accumulators are VGPR variables, and hipcc may move them right behind the K-step without the
   // result-latency padding an asm MFMA does not get (seen: three of the four fragments wrong); 32 MFMAs later they are written
   band_tap_mfma<8>(acc8, fa, frag8(bf[8][0], bf[8][1]));
@@ -131,6 +154,7 @@ __device__ __forceinline__ void band_kstep(f32x4 (&acc8)[4], const uint32_t abas
   band_tap_mfma<5>(acc8, fa, frag8(bf[5][0], bf[5][1]));
   band_tap_mfma<6>(acc8, fa, frag8(bf[6][0], bf[6][1]));
   band_tap_mfma<7>(acc8, fa, frag8(bf[7][0], bf[7][1]));
+#endif
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -139,7 +163,7 @@ template <class Cfg>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k, const BandK bk) {
   constexpr uint32_t FAR = 0x80000000u;
   constexpr int W = Cfg::W, R = Cfg::R, PW = Cfg::PW;
-  static_assert(Cfg::KSPLIT && Cfg::NS == 7, "the K-step lists below are written for the 56-wide band");
+  static_assert(Cfg::KSPLIT ? Cfg::NS == 7 : Cfg::NS == 4, "the K-step lists below are written for the 56- and 28-wide bands");
   __shared__ __attribute__((aligned(16))) char smem[2 * Cfg::BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -156,8 +180,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
   // 16 bytes of channel half l & 1 of slot l >> 1.  Offsets relative to the band's first output pixel, fixed for the kernel.
   int relx[Cfg::NXJ];
   uint32_t reld[Cfg::NDJ];
-  uint32_t xcls = 0;            // 2 bits per jj: 0 inside, 1 the row above the band, 2 the row below, 3 never (padding slot)
-  uint32_t dok = 0;
+  uint32_t xnever = 0, xtop = 0, xbot = 0;      // bit jj: a padding slot / a slot of the row above the band / of the row below
+  uint32_t dbad = 0;
 #pragma unroll
   for (int jj = 0; jj < Cfg::NXJ; ++jj) {
     const int id = wave + 8 * jj;
@@ -166,7 +190,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
     const int ir = xi / PW, ic = xi % PW - 1;
     const bool ok = ic >= 0 && ic < W && ir < R + 2;
     relx[jj] = (((ir - 1) * W + ic) * k.xld + k.xoff + cb * 16 + hf * 8) * 2;
-    xcls |= (uint32_t)(!ok ? 3 : ir == 0 ? 1 : ir == R + 1 ? 2 : 0) << (2 * jj);
+    xnever |= (uint32_t)!ok << jj;
+    xtop |= (uint32_t)(ok && ir == 0) << jj;
+    xbot |= (uint32_t)(ok && ir == R + 1) << jj;
   }
 #pragma unroll
   for (int jj = 0; jj < Cfg::NDJ; ++jj) {
@@ -174,22 +200,29 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
     const int cob = id / Cfg::DCH, n = id % Cfg::DCH;
     const int p = 32 * n + (lane >> 1), hf = lane & 1;
     reld[jj] = (uint32_t)((p * k.dld + k.doff + cob * 16 + hf * 8) * 2);
-    dok |= (uint32_t)(p < Cfg::NPX) << jj;
+    dbad |= (uint32_t)(p >= Cfg::NPX) << jj;
   }
-  auto issue_band = [&](const int u, const int buf) __attribute__((always_inline)) {
+  // the band being fetched: scalars set once per band (band_next), its DMA slots (X instructions, then dY) issued in chunks
+  int nx_xbase = 0, nx_dbase = 0, nx_buf = 0;
+  uint32_t nx_bad = 0;            // bit jj: X slot jj of this lane reads padding in this band (branch-free: FAR is OR-ed in)
+  bool nx_on = false;
+  auto band_next = [&](const int u, const int buf, const bool on) __attribute__((always_inline)) {
     const int band = u / Cfg::NHALF, half = u % Cfg::NHALF;
     const int f = band / bk.bpf, hb = band - f * bk.bpf;
     const int pix0 = (f * k.xh + hb * R) * W;
-    const bool top_ok = hb > 0, bot_ok = hb < bk.bpf - 1;
-    const int xbase = pix0 * k.xld * 2 + half * 128, dbase = pix0 * k.dld * 2;
-    char* const base = smem + buf * Cfg::BUF;
+    nx_bad = xnever | (hb > 0 ? 0u : xtop) | (hb < bk.bpf - 1 ? 0u : xbot);
+    nx_xbase = pix0 * k.xld * 2 + half * 128; nx_dbase = pix0 * k.dld * 2;
+    nx_buf = buf; nx_on = on && SFK_BAND_EXP != 2;
+  };
+  constexpr int NSLOT = Cfg::NXJ + Cfg::NDJ;
+  auto issue_slots = [&](const int lo, const int hi_) __attribute__((always_inline)) {
+    if (!nx_on) return;
+    char* const base = smem + nx_buf * Cfg::BUF;
 #pragma unroll
     for (int jj = 0; jj < Cfg::NXJ; ++jj) {
       const int id = wave + 8 * jj;
-      if (id < Cfg::NXI) {
-        const uint32_t cls = (xcls >> (2 * jj)) & 3;
-        const bool ok = cls == 0 || (cls == 1 && top_ok) || (cls == 2 && bot_ok);
-        const uint32_t vo = ok ? (uint32_t)(xbase + relx[jj]) : FAR;
+      if (jj >= lo && jj < hi_ && id < Cfg::NXI) {
+        const uint32_t vo = (uint32_t)(nx_xbase + relx[jj]) | (((nx_bad >> jj) & 1u) << 31);      // (valid offsets < 0x7FF00000)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_wb_t*)(base + (id / Cfg::XCH) * Cfg::XPLANE + (id % Cfg::XCH) * 1024), 16,
                                                  (int)vo, 0, 0, 0);
       }
@@ -197,8 +230,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
 #pragma unroll
     for (int jj = 0; jj < Cfg::NDJ; ++jj) {
       const int id = wave + 8 * jj;
-      if (id < Cfg::NDI) {
-        const uint32_t vo = ((dok >> jj) & 1) ? (uint32_t)dbase + reld[jj] : FAR;
+      if (Cfg::NXJ + jj >= lo && Cfg::NXJ + jj < hi_ && id < Cfg::NDI) {
+        const uint32_t vo = ((uint32_t)nx_dbase + reld[jj]) | (((dbad >> jj) & 1u) << 31);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_wb_t*)(base + Cfg::XBYTES + (id / Cfg::DCH) * Cfg::DPLANE + (id % Cfg::DCH) * 1024),
                                                  16, (int)vo, 0, 0, 0);
       }
@@ -206,12 +239,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
   };
 
   // ---- transposed-read addresses: lane (g4, q, p4) reads pixel 4 g4 + q of a 16-pixel half K-step, channels 4 p4 .. 4 p4 + 3
-  // A wave runs the EVEN K-steps of the bands in buffer kg and the ODD ones of the bands in buffer kg ^ 1 (global K-step parity
-  // = kg, 7 K-steps per band): one address register per (K-step, read) with the buffer folded in.
+  // KSPLIT (64 output channels): a wave runs the EVEN K-steps of the bands in buffer kg and the ODD ones of the bands in buffer
+  // kg ^ 1 (global K-step parity = kg, 7 K-steps per band): one address register per (K-step, read) with the buffer folded in.
+  // Otherwise (128 output channels: kg picks the wave's four co blocks) every wave runs every K-step and the registers move
+  // to the other buffer after each band.
   const int g4 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_wb_t*)smem;
-  const uint32_t a_lane = lds0 + (uint32_t)(Cfg::XBYTES + (4 * g4 + q) * 32 + p4 * 8);
-  const uint32_t a_even = a_lane + (uint32_t)(kg * Cfg::BUF), a_odd = a_lane + (uint32_t)((kg ^ 1) * Cfg::BUF);
+  const uint32_t a_lane = lds0 + (uint32_t)(Cfg::XBYTES + (Cfg::KSPLIT ? 0 : 4 * kg * Cfg::DPLANE) + (4 * g4 + q) * 32 + p4 * 8);
+  uint32_t a_even = a_lane + (uint32_t)(Cfg::KSPLIT ? kg * Cfg::BUF : 0);
+  const uint32_t a_odd = a_lane + (uint32_t)((kg ^ 1) * Cfg::BUF);
   uint32_t xb[Cfg::NS][2];
 #pragma unroll
   for (int s = 0; s < Cfg::NS; ++s)
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
     for (int r = 0; r < 2; ++r) {
       const int p = 32 * s + 16 * r + 4 * g4 + q;
       const int pr = p / W, pc = p - pr * W;
-      xb[s][r] = lds0 + (uint32_t)((((s & 1) ^ kg) * Cfg::BUF) + wc * Cfg::XPLANE + (pr * PW + pc) * 32 + p4 * 8);
+      xb[s][r] = lds0 + (uint32_t)((Cfg::KSPLIT ? ((s & 1) ^ kg) * Cfg::BUF : 0) + wc * Cfg::XPLANE + (pr * PW + pc) * 32 + p4 * 8);
     }
 
   f32x4 acc8[4];
@@ -234,66 +270,97 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const WgradK k,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < nit) issue_band(lb + (it + 1) * grid, (it + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
+    band_next(lb + (it + 1) * grid, (it + 1) & 1, it + 1 < nit);
   };
-  auto even_steps = [&]() __attribute__((always_inline)) {
-    band_kstep<Cfg, 0>(acc8, a_even, xb[0][0], xb[0][1]);
-    band_kstep<Cfg, 2>(acc8, a_even, xb[2][0], xb[2][1]);
-    band_kstep<Cfg, 4>(acc8, a_even, xb[4][0], xb[4][1]);
-    band_kstep<Cfg, 6>(acc8, a_even, xb[6][0], xb[6][1]);
-  };
-  auto odd_steps = [&]() __attribute__((always_inline)) {
-    band_kstep<Cfg, 1>(acc8, a_odd, xb[1][0], xb[1][1]);
-    band_kstep<Cfg, 3>(acc8, a_odd, xb[3][0], xb[3][1]);
-    band_kstep<Cfg, 5>(acc8, a_odd, xb[5][0], xb[5][1]);
-  };
-  issue_band(lb, 0);
-  for (int it = 0; it < nit; ++it) {
-    band_top(it);
-    if (((it & 1) ^ kg) == 0) even_steps(); else odd_steps();
+  const bool hi = kg == 0;
+#define SFK_BAND_DMA(C, N) [&]() __attribute__((always_inline)) { issue_slots((C) * NSLOT / (N), ((C) + 1) * NSLOT / (N)); }
+  band_next(lb, 0, true);
+  nx_on = true;                                  // (the first band is fetched in every experiment build)
+  issue_slots(0, NSLOT);
+  if constexpr (Cfg::KSPLIT) {
+    for (int it = 0; it < nit; ++it) {
+      band_top(it);
+      if (((it & 1) ^ kg) == 0) {
+        band_kstep<Cfg, 0>(acc8, a_even, xb[0][0], xb[0][1], hi, SFK_BAND_DMA(0, 4));
+        band_kstep<Cfg, 2>(acc8, a_even, xb[2][0], xb[2][1], hi, SFK_BAND_DMA(1, 4));
+        band_kstep<Cfg, 4>(acc8, a_even, xb[4][0], xb[4][1], hi, SFK_BAND_DMA(2, 4));
+        band_kstep<Cfg, 6>(acc8, a_even, xb[6][0], xb[6][1], hi, SFK_BAND_DMA(3, 4));
+      } else {
+        band_kstep<Cfg, 1>(acc8, a_odd, xb[1][0], xb[1][1], hi, SFK_BAND_DMA(0, 3));
+        band_kstep<Cfg, 3>(acc8, a_odd, xb[3][0], xb[3][1], hi, SFK_BAND_DMA(1, 3));
+        band_kstep<Cfg, 5>(acc8, a_odd, xb[5][0], xb[5][1], hi, SFK_BAND_DMA(2, 3));
+      }
+    }
+  } else {
+    for (int it = 0; it < nit; ++it) {
+      band_top(it);
+      band_kstep<Cfg, 0>(acc8, a_even, xb[0][0], xb[0][1], hi, SFK_BAND_DMA(0, 4));
+      band_kstep<Cfg, 1>(acc8, a_even, xb[1][0], xb[1][1], hi, SFK_BAND_DMA(1, 4));
+      band_kstep<Cfg, 2>(acc8, a_even, xb[2][0], xb[2][1], hi, SFK_BAND_DMA(2, 4));
+      band_kstep<Cfg, 3>(acc8, a_even, xb[3][0], xb[3][1], hi, SFK_BAND_DMA(3, 4));
+      const uint32_t d = (it & 1) ? (uint32_t)(-Cfg::BUF) : (uint32_t)Cfg::BUF;       // to the other buffer
+      a_even += d;
+#pragma unroll
+      for (int s = 0; s < Cfg::NS; ++s) { xb[s][0] += d; xb[s][1] += d; }
+    }
   }
+#undef SFK_BAND_DMA
 
-  // ---- the two K halves meet: kg = 1 leaves its fragments in LDS (the band buffers are dead), kg = 0 adds and stores
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // asm MFMAs carry no result-latency padding for the readers below
-  __syncthreads();
-  float4* const ex = reinterpret_cast<float4*>(smem);
-  // (fragment by fragment: with all 144 values in VGPRs at once hipcc spills into AGPRs it believes free -- ours)
-  if (kg == 1) {
+  // partial of this workgroup: fragment F = (co block * 9 + tap position) * 4 + ci block, 64 float4 each (band_reduce_kernel);
+  // with two input-channel halves workgroup lb = (split lb >> 1, half lb & 1): the same image order
+  float4* const wp = k.ws + (int64_t)lb * (Cfg::NFRAG * 64) + lane;
+  if constexpr (Cfg::KSPLIT) {
+    // ---- the two K halves meet: kg = 1 leaves its fragments in LDS (the band buffers are dead), kg = 0 adds and stores
+    // (fragment by fragment: with all 144 values in VGPRs at once hipcc spills into AGPRs it believes free -- ours)
+    __syncthreads();
+    float4* const ex = reinterpret_cast<float4*>(smem);
+    if (kg == 1) {
 #define SFK_BAND_PUT(T, C) { const f32x4 v = band_acc_read<4 * T + C>(); ex[(wc * 36 + C * 9 + T) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]); }
 #define SFK_BAND_PUT4(T) SFK_BAND_PUT(T, 0) SFK_BAND_PUT(T, 1) SFK_BAND_PUT(T, 2) SFK_BAND_PUT(T, 3)
-    SFK_BAND_PUT4(0) SFK_BAND_PUT4(1) SFK_BAND_PUT4(2) SFK_BAND_PUT4(3) SFK_BAND_PUT4(4) SFK_BAND_PUT4(5) SFK_BAND_PUT4(6) SFK_BAND_PUT4(7)
+      SFK_BAND_PUT4(0) SFK_BAND_PUT4(1) SFK_BAND_PUT4(2) SFK_BAND_PUT4(3) SFK_BAND_PUT4(4) SFK_BAND_PUT4(5) SFK_BAND_PUT4(6) SFK_BAND_PUT4(7)
 #undef SFK_BAND_PUT4
 #undef SFK_BAND_PUT
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ex[(wc * 36 + c * 9 + 8) * 64 + lane] = make_float4(acc8[c][0], acc8[c][1], acc8[c][2], acc8[c][3]);
-  }
-  __syncthreads();
-  if (kg == 0) {
-    // partial of this workgroup: fragment F = (co block * 9 + tap position) * 4 + ci block, 64 float4 each (band_reduce_kernel)
-    float4* const wp = k.ws + (int64_t)lb * (Cfg::NFRAG * 64) + lane;
+      for (int c = 0; c < 4; ++c) ex[(wc * 36 + c * 9 + 8) * 64 + lane] = make_float4(acc8[c][0], acc8[c][1], acc8[c][2], acc8[c][3]);
+    }
+    __syncthreads();
+    if (kg == 0) {
 #define SFK_BAND_OUT(T, C) { const f32x4 v = band_acc_read<4 * T + C>(); const float4 o = ex[(wc * 36 + C * 9 + T) * 64 + lane]; \
-      wp[((C * 9 + bk.tpos[T]) * 4 + wc) * 64] = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w); }
+        wp[((C * 9 + bk.tpos[T]) * 4 + wc) * 64] = make_float4(v[0] + o.x, v[1] + o.y, v[2] + o.z, v[3] + o.w); }
+#define SFK_BAND_OUT4(T) SFK_BAND_OUT(T, 0) SFK_BAND_OUT(T, 1) SFK_BAND_OUT(T, 2) SFK_BAND_OUT(T, 3)
+      SFK_BAND_OUT4(0) SFK_BAND_OUT4(1) SFK_BAND_OUT4(2) SFK_BAND_OUT4(3) SFK_BAND_OUT4(4) SFK_BAND_OUT4(5) SFK_BAND_OUT4(6) SFK_BAND_OUT4(7)
+#undef SFK_BAND_OUT4
+#undef SFK_BAND_OUT
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 o = ex[(wc * 36 + c * 9 + 8) * 64 + lane];
+        wp[((c * 9 + bk.tpos[8]) * 4 + wc) * 64] = make_float4(acc8[c][0] + o.x, acc8[c][1] + o.y, acc8[c][2] + o.z, acc8[c][3] + o.w);
+      }
+    }
+  } else {
+    // every wave owns its 36 fragments: co blocks 4 kg .. 4 kg + 3
+#define SFK_BAND_OUT(T, C) { const f32x4 v = band_acc_read<4 * T + C>(); \
+      wp[(((4 * kg + C) * 9 + bk.tpos[T]) * 4 + wc) * 64] = make_float4(v[0], v[1], v[2], v[3]); }
 #define SFK_BAND_OUT4(T) SFK_BAND_OUT(T, 0) SFK_BAND_OUT(T, 1) SFK_BAND_OUT(T, 2) SFK_BAND_OUT(T, 3)
     SFK_BAND_OUT4(0) SFK_BAND_OUT4(1) SFK_BAND_OUT4(2) SFK_BAND_OUT4(3) SFK_BAND_OUT4(4) SFK_BAND_OUT4(5) SFK_BAND_OUT4(6) SFK_BAND_OUT4(7)
 #undef SFK_BAND_OUT4
 #undef SFK_BAND_OUT
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 o = ex[(wc * 36 + c * 9 + 8) * 64 + lane];
-      wp[((c * 9 + bk.tpos[8]) * 4 + wc) * 64] = make_float4(acc8[c][0] + o.x, acc8[c][1] + o.y, acc8[c][2] + o.z, acc8[c][3] + o.w);
-    }
+    for (int c = 0; c < 4; ++c)
+      wp[(((4 * kg + c) * 9 + bk.tpos[8]) * 4 + wc) * 64] = make_float4(acc8[c][0], acc8[c][1], acc8[c][2], acc8[c][3]);
   }
 }
 
 // dw[co][widx][ci] += sum over the workgroups' partials, in workgroup order per split group and then group order: the summation
 // tree is fixed by (splits, ZG).  A block owns 256 / ZG consecutive float4 of the partial image.
+// Partial image of a split: [input-channel half][fragment][lane]; nfrag fragments per half.
 template <int ZG>
-__global__ __launch_bounds__(256) void band_reduce_kernel(const WgradK k, const int nfrag, const int splits) {
+__global__ __launch_bounds__(256) void band_reduce_kernel(const WgradK k, const int nfrag, const int nhalf, const int splits) {
   constexpr int E = 256 / ZG;
   __shared__ float4 red[ZG][E];
   const int le = threadIdx.x % E, zg = threadIdx.x / E;
-  const int idx = blockIdx.x * E + le, total = nfrag * 64;
+  const int idx = blockIdx.x * E + le, total = nhalf * nfrag * 64;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < total) {
     const float4* p = k.ws + idx;
@@ -322,9 +389,9 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const WgradK k, const 
     }
   }
   if (idx >= total) return;
-  const int lane = idx & 63, F = idx >> 6;
+  const int lane = idx & 63, half = (idx >> 6) / nfrag, F = (idx >> 6) - half * nfrag;
   const int cib = F & 3, tp = (F >> 2) % 9, cbo = (F >> 2) / 9;
-  const int co0 = cbo * 16 + 4 * (lane >> 4), ci = cib * 16 + (lane & 15);
+  const int co0 = cbo * 16 + 4 * (lane >> 4), ci = half * 64 + cib * 16 + (lane & 15);
   const int widx = k.taps[tp].widx;
   float* dp = k.dw + ((int64_t)co0 * k.wtaps + widx) * k.cin + ci;
   const int64_t rs = (int64_t)k.wtaps * k.cin;
@@ -336,10 +403,14 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const WgradK k, const 
   for (int r = 0; r < 4; ++r) dp[r * rs] = old[r] + v4[r];
 }
 
-// eligibility: bf16, (1,3,3) "same" stride-1 taps over frames of 56 x 56, 64 -> 64
+// eligibility: bf16, (1,3,3) "same" stride-1 taps; 64 -> 64 over frames of 56 x 56 (slow res2 conv_b) or 128 -> 128 over 28 x 28
+// (slow res3 conv_b: two workgroups per band, 64 input channels each, all 128 output channels)
 __attribute__((visibility("hidden"))) bool wgrad_band_ok(const sfk_wgrad_desc* d) {
-  if (!sfk_tune().wgrad_band || d->x.dtype != SFK_BF16 || d->dy.dtype != SFK_BF16 || d->dg_w) return false;
-  if (d->cin != 64 || d->cout != 64 || d->x.w != 56) return false;
+  const int on = sfk_tune().wgrad_band;
+  if (!on || d->x.dtype != SFK_BF16 || d->dy.dtype != SFK_BF16 || d->dg_w) return false;
+  const bool c64 = (on & 1) && d->cin == 64 && d->cout == 64 && d->x.w == 56;
+  const bool c128 = (on & 2) && d->cin == 128 && d->cout == 128 && d->x.w == 28;
+  if (!c64 && !c128) return false;
   if (d->x.h % 4 != 0 || d->x.n != d->dy.n || d->x.t != d->dy.t || d->x.h != d->dy.h || d->x.w != d->dy.w) return false;
   if (d->gs[0] != 1 || d->gs[1] != 1 || d->gs[2] != 1 || d->ntaps != 9) return false;
   int seen = 0;
@@ -354,25 +425,29 @@ __attribute__((visibility("hidden"))) bool wgrad_band_ok(const sfk_wgrad_desc* d
   return sfk_fmap_bytes(&d->x) < 0x7FF00000ll && sfk_fmap_bytes(&d->dy) < 0x7FF00000ll;
 }
 
-__attribute__((visibility("hidden"))) int launch_wgrad_band(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
-  using Cfg = BandCfg<56, 64, 64>;
+template <class Cfg>
+static int launch_band_cfg(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
   BandK bk;
   bk.bpf = d->x.h / 4;
-  bk.nunits = d->x.n * d->x.t * bk.bpf;
+  bk.nunits = d->x.n * d->x.t * bk.bpf * Cfg::NHALF;
   for (int i = 0; i < 9; ++i) bk.tpos[(d->taps[i].dh + 1) * 3 + d->taps[i].dw + 1] = i;
-  const int grid = bk.nunits < 256 ? bk.nunits : 256;
+  const int grid = (bk.nunits < 256 ? bk.nunits : 256) / Cfg::NHALF * Cfg::NHALF;     // (a workgroup keeps its channel half)
   const int64_t need = (int64_t)grid * Cfg::NFRAG * 64 * 16;
   if (dry) { *dry = need; return SFK_OK; }
   if (!k.ws || need > d->workspace_bytes) return SFK_ERR_UNSUPPORTED;      // (the caller falls back to the implicit-GEMM kernels)
   hipLaunchKernelGGL((conv_wgrad_band_kernel<Cfg>), dim3((unsigned)grid), dim3(512), 0, s, k, bk);
   SFK_CHECK_LAUNCH();
-  const int total = Cfg::NFRAG * 64;
-  if (grid >= 32)
-    hipLaunchKernelGGL((band_reduce_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, k, Cfg::NFRAG, grid);
+  const int total = Cfg::NHALF * Cfg::NFRAG * 64, splits = grid / Cfg::NHALF;
+  if (splits >= 32)
+    hipLaunchKernelGGL((band_reduce_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, k, Cfg::NFRAG, Cfg::NHALF, splits);
   else
-    hipLaunchKernelGGL((band_reduce_kernel<1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, Cfg::NFRAG, grid);
+    hipLaunchKernelGGL((band_reduce_kernel<1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, Cfg::NFRAG, Cfg::NHALF, splits);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
+}
+
+__attribute__((visibility("hidden"))) int launch_wgrad_band(WgradK& k, const sfk_wgrad_desc* d, hipStream_t s, int64_t* dry) {
+  return d->cin == 64 ? launch_band_cfg<BandCfg<56, 64, 64>>(k, d, s, dry) : launch_band_cfg<BandCfg<28, 128, 128>>(k, d, s, dry);
 }
 
 }  // namespace sfk_wgrad
