@@ -39,8 +39,8 @@ extern "C" {
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 (retired in 15); 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
- * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band. */
-#define SFK_ABI_VERSION 16
+ * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band; 17 = sfk_tuning.stem_v3. */
+#define SFK_ABI_VERSION 17
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -501,6 +501,8 @@ typedef struct {
   int32_t wgrad_band;         /* 3:    the LDS-band filter-gradient kernel (whole dW in the workgroups' accumulators, partials through the
                                          workspace: conv_wgrad_band.hip): bit 0: 64 -> 64 (1,3,3) over 56 x 56 frames (slow res2 conv_b);
                                          bit 1: 128 -> 128 over 28 x 28 (slow res3 conv_b)                                  */
+  int32_t stem_v3;            /* 1:    bit 0: the input-frame-stationary forward of the canonical fast stem (filter in registers, one LDS
+                                         pixel run per three MFMAs: stem_fwd_v3_kernel)                                    */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

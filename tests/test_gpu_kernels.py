@@ -440,12 +440,14 @@ STEM_CASES = [
     (3, 8, 5, (2, 6, 40, 48), None, None),                  # fast stem, 16-byte rows: the frame-stationary kernels (bf16)
     (3, 8, 5, (1, 9, 72, 64), None, [0, 2, 3, 5, 8, 8, 1]), # the same through a frame index, 36x32 output, 3x2 tiles
     (3, 8, 3, (2, 4, 32, 32), None, None),                  # kt = 3 on the frame-stationary path
+    (3, 8, 5, (1, 21, 40, 48), None, None),                 # 11 output pairs = two temporal units (8 + 3), odd clip length
+    (3, 8, 3, (1, 19, 32, 40), None, None),                 # the same for kt = 3
 ]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("src_dtype", DTYPES, ids=["src_f32", "src_bf16"])
-@pytest.mark.parametrize("case", STEM_CASES, ids=["fast5x7x7", "slow_tindex", "ref_slow", "ref_fast", "fast5_rows16", "fast5_tindex", "fast3_rows16"])
+@pytest.mark.parametrize("case", STEM_CASES, ids=["fast5x7x7", "slow_tindex", "ref_slow", "ref_fast", "fast5_rows16", "fast5_tindex", "fast3_rows16", "fast5_units", "fast3_units"])
 def test_stem_conv_direct(hip, dtype, src_dtype, case):
     cin, cout, kt, (n, t, h, w), chan, tidx = case
     gen = torch.Generator().manual_seed(17)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 16       # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 17       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -197,7 +197,7 @@ class _Tuning(C.Structure):
                 ("nt_reduce_mb", C.c_int32), ("nt_bwd_apply_mb", C.c_int32), ("igemm_pw_stream", C.c_int32),
                 ("pool_blocks", C.c_int64), ("igemm_tile256", C.c_int32), ("wgrad_target_gen", C.c_int32),
                 ("wgrad_target_256", C.c_int32), ("wgrad_min_stages_256", C.c_int32), ("igemm_p8", C.c_int32),
-                ("wgrad_p8", C.c_int32), ("igemm_halo", C.c_int32), ("wgrad_band", C.c_int32)]
+                ("wgrad_p8", C.c_int32), ("igemm_halo", C.c_int32), ("wgrad_band", C.c_int32), ("stem_v3", C.c_int32)]
 
 
 # experiment knobs (tools/gpu_ab_env.sh): read HERE, once, on the host side of the boundary -- the library itself never
@@ -208,7 +208,7 @@ TUNING_ENV = {"SFK_KSHORT": "igemm_short_k", "SFK_SMALLK": "igemm_small_k", "SFK
               "SFK_NT_RED_MB": "nt_reduce_mb", "SFK_NT_BAPP_MB": "nt_bwd_apply_mb", "SFK_POOL_BLOCKS": "pool_blocks",
               "SFK_PW_STREAM": "igemm_pw_stream", "SFK_TILE256": "igemm_tile256", "SFK_WGTG": "wgrad_target_gen",
               "SFK_P8": "igemm_p8",
-              "SFK_WGP8": "wgrad_p8", "SFK_HALO": "igemm_halo", "SFK_WGBAND": "wgrad_band"}
+              "SFK_WGP8": "wgrad_p8", "SFK_HALO": "igemm_halo", "SFK_WGBAND": "wgrad_band", "SFK_STEM3": "stem_v3"}
 
 _PF, _PV, _I32, _I64, _F = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _P_FMAP = C.POINTER(_FMap)

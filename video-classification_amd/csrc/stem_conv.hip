@@ -11,6 +11,10 @@
 // index (PackPathway), as f32 or bf16.
 #include "sfk_common.h"
 
+#ifndef SFK_STEM_EXP
+#define SFK_STEM_EXP 0     // timing experiments on stem_fwd_v3_kernel (results wrong): 1 no MFMAs, 2 no epilogue, 3 no per-pair fetch / stage, 4 no pixel-run reads
+#endif
+
 namespace {
 
 constexpr int TS = 16;            // output tile edge (pixels)
@@ -582,6 +586,236 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v2_kernel(const StemK k, int 
   }
 }
 
+// 16-lane row sum with DPP shifts (4 vector instructions; __shfl_xor goes through ds_bpermute): the total ends in lane 15
+__device__ __forceinline__ float stem_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ forward, v3
+// stem_fwd_v2_kernel is LDS-bound: every MFMA takes its own 16-byte pixel run (4-byte aligned: four ds_read_b32) from the ring,
+// 8 LDS cycles per 16-cycle MFMA and wave, four waves' worth per CU -- 2.5 x the matrix pipe's time (540 us for the metric
+// geometry against ~110 us of MFMAs).  v3 is INPUT-FRAME stationary: an input frame (2m + par) feeds every output pair it
+// reaches at once -- pairs m - 1, m, m + 1 (kt = 5) -- so one pixel run is read ONCE for up to three MFMAs (18 instead of 6
+// per 16 bytes), the three pairs' accumulators roll through registers (pair m - 1 is complete after input pair m and is
+// stored), and the filter lives in REGISTERS: the 36 A fragments (f', chunk) of the v2 matrix, where an input frame of
+// parity par meets pair m - 1 + r at window position f' = par + 2 - 2 r + PT.  LDS holds only the current and the next
+// input pair (4 frame patches); the ring of kt + 1 frames and its rotation are gone.
+// A unit is (clip, 16 x 16 output tile, chunk of output pairs p0 .. p1 - 1) and walks input pairs p0 - 1 .. p1 (the two
+// boundary pairs feed one output pair each); frames outside the clip are skipped.
+template <int CIN, int KT>
+__global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int pairs_per_unit, int nunits) {
+  constexpr int NF = KT + 1, PT = KT / 2;
+  constexpr int SLOT = CIN * F2_PLANE;
+  constexpr int CPF = CIN * 2;
+  constexpr int NCH = NF * CPF;
+  constexpr int FRAME_CHUNKS = CIN * F2_PR * 6;
+  constexpr int NXC = (2 * FRAME_CHUNKS + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
+  char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [2][8 waves][16 rows][2]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16_t* yp = static_cast<bf16_t*>(k.y);
+  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
+  const int perm_g = ((g & 1) << 1) | (g >> 1);                  // {0,2,1,3}
+
+  // ---- A matrix as in v2: amat[chunk f'*CPF + c6][row (jt,co)][k = 8g + k'] = w[co][f'-jt][ci = c6>>1][kh][k'-1]
+  {
+    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
+    for (int e = tid; e < NCH * 64; e += 512) {
+      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
+      const int fp = ch / CPF, c6 = ch % CPF;
+      const int jt = row >> 3, co = row & 7, f = fp - jt;
+      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+      if (f >= 0 && f < KT && co < k.cout && kh < KH) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + ((f * CIN + ci) * KH + kh) * 8);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
+      }
+      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
+    }
+  }
+  __syncthreads();
+  bf16x8 afr[NCH];
+  {
+    const int a_lane = a_off(l15, g);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
+      asm volatile("" : "+v"(afr[ch]));             // loop-invariant registers, not re-loadable values
+    }
+  }
+
+  // ---- staging: three 16-byte chunks per thread and input pair, each load instruction within ONE frame so that the frame's
+  // base offset rides the instruction's scalar offset and the per-thread part (channel, patch row, chunk) is a 32-bit voffset
+  // computed once per unit (the first version rebuilt a 64-bit address per chunk and pair: ~100 vector instructions per pair
+  // and wave, a quarter of the kernel's time).  Slot 0 / 1: chunk tid of frame 0 / 1; slot 2: chunk 512 + (tid & 255) of frame
+  // tid >> 8 (waves 0-3 / 4-7).  Padding: a voffset past the resource reads zeros (the scalar offset is not range-checked);
+  // a frame outside the clip reads through a zero-sized resource.
+  static_assert(FRAME_CHUNKS > 512 && FRAME_CHUNKS <= 768, "three single-frame loads per thread cover a pair");
+  int x_row[3], x_col[3], x_chan[3], x_loc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = i < 2 ? tid : 512 + (tid & 255);
+    const int fr = i < 2 ? i : tid >> 8;
+    const int ci = e / (F2_PR * 6), rr = e % (F2_PR * 6);
+    x_row[i] = e < FRAME_CHUNKS ? rr / 6 : -1000000;               // (an unused slot is always out of range)
+    x_col[i] = 8 * (rr % 6);
+    x_chan[i] = (int)(ci * k.sc * 2);
+    x_loc[i] = fr * SLOT + ci * F2_PLANE + (rr / 6) * F2_PITCH + (rr % 6) * 16;
+  }
+  uint32_t xv[3];                                                // voffsets of the current unit
+  uint4 xr[3];
+  int n = 0, ho0 = 0, wo0 = 0;
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
+  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
+  auto unit_offsets = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int hi = 2 * ho0 - 3 + x_row[i], wi = 2 * wo0 - 8 + x_col[i];
+      const bool ok = (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      xv[i] = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
+    }
+  };
+  auto fetch = [&](int F0) {        // frames F0, F0 + 1 (logical)
+    uint32_t so[2];
+    bool fok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int F = F0 + u;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fok[u] = f >= 0 && f < k.t_in;
+      so[u] = fok[u] ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f * k.st) * 2) : 0u;
+    }
+    const int u2 = wave >> 2;                                    // slot 2's frame (wave-uniform)
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(fok[0] ? srs : srs0, (int)xv[0], (int)so[0], 0);
+    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(fok[1] ? srs : srs0, (int)xv[1], (int)so[1], 0);
+    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128((u2 ? fok[1] : fok[0]) ? srs : srs0, (int)xv[2], (int)(u2 ? so[1] : so[0]), 0);
+    xr[0] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+    xr[1] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+    xr[2] = make_uint4(v2[0], v2[1], v2[2], v2[3]);
+  };
+  auto stage = [&](int buf) {
+    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[0]) = xr[0];
+    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[1]) = xr[1];
+    if (x_row[2] >= 0) *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[2]) = xr[2];
+  };
+
+  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
+  const int tpairs = (k.t_log + 1) / 2;
+  const int tchunks = (tpairs + pairs_per_unit - 1) / pairs_per_unit;
+
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int tc = unit % tchunks;
+    int tile = unit / tchunks, th, tw;
+    tw = tile % k.tiles_w; tile /= k.tiles_w;
+    th = tile % k.tiles_h;
+    n = tile / k.tiles_h;
+    ho0 = th * TS; wo0 = tw * TS;
+    const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);
+    unit_offsets();
+    __syncthreads();                                   // the previous unit's patch reads are done
+    fetch(2 * (p0 - 1));
+    stage(0);
+    __syncthreads();
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur = 0;
+    for (int m = p0 - 1; m <= p1; ++m) {
+      if (m < p1 && SFK_STEM_EXP != 3) fetch(2 * (m + 1));                  // the next input pair flies during this pair's MFMAs
+      const bool on[3] = {m - 1 >= p0, m >= p0 && m < p1, m + 1 < p1};      // is output pair m - 1 + r inside this unit?
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int F = 2 * m + par;
+        if (F < 0 || F >= k.t_log) continue;           // temporal padding (wave-uniform)
+        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
+#pragma unroll
+        for (int c6 = 0; c6 < CPF; ++c6) {
+          bf16x8 bv[2];
+#if SFK_STEM_EXP == 4
+          bv[0] = afr[c6]; bv[1] = afr[c6 + 6];
+#else
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * F2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
+            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
+            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
+          }
+#endif
+#if SFK_STEM_EXP == 1
+          asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
+#else
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            // window position of this frame for pair m - 1 + r (a literal after unrolling).  Pairs outside the unit are
+            // multiplied too: their accumulators roll out unstored, and a branch per pair made hipcc shuffle all 24
+            // accumulator registers around every MFMA pair (1,137 us against v2's 562)
+            const int fp = par + 2 - 2 * r + PT;
+            if (fp >= 0 && fp < NF) {
+              acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[0], acc[r][0], 0, 0, 0);
+              acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[1], acc[r][1], 0, 0, 0);
+            }
+          }
+#endif
+        }
+      }
+      // ---- output pair m - 1 is complete: lane holds rows 4g..4g+3 = (jt = g>>1, co = 4*(g&1) + r) of pixel (2*wave + j, l15)
+      const int to0 = 2 * (m - 1);
+      float* redp = red + (m & 1) * (8 * 16 * 2);
+      if (on[0] && (SFK_STEM_EXP != 2 || m == p1)) {
+        const int jt = g >> 1, co0 = 4 * (g & 1), to = to0 + jt;
+        const int wo = wo0 + l15;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ho = ho0 + 2 * wave + j;
+          if (to < k.t_out && ho < k.ho && wo < k.wo && co0 < k.cout) {
+            store4(yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + co0, acc[0][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] += acc[0][j][r]; s2[r] += acc[0][j][r] * acc[0][j][r]; }
+          }
+        }
+        if (k.stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = stem_row16_sum(s1[r]), c = stem_row16_sum(s2[r]);      // DPP row shifts: the total ends in lane 15 of the row
+            if (l15 == 15) {
+              redp[(wave * 16 + 4 * g + r) * 2 + 0] = a;
+              redp[(wave * 16 + 4 * g + r) * 2 + 1] = c;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      if (m < p1 && SFK_STEM_EXP != 3) stage(cur ^ 1);
+      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged, red is complete
+      if (on[0] && k.stats && tid < 16) {
+        const int sjt = tid >> 3, sco = tid & 7, sto = to0 + sjt;
+        if (sto < k.t_out && sco < k.cout) {
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < 8; ++w_) { a1 += redp[(w_ * 16 + tid) * 2]; a2 += redp[(w_ * 16 + tid) * 2 + 1]; }
+          const int64_t trow = (((int64_t)n * k.t_out + sto) * k.tiles_h + th) * k.tiles_w + tw;
+          k.stats[(trow * k.cout + sco) * 2 + 0] = a1;
+          k.stats[(trow * k.cout + sco) * 2 + 1] = a2;
+        }
+      }
+      cur ^= 1;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ filter gradient, v2
 // The canonical fast stem (5x7x7, 3 -> 8 channels) is where the generic kernel above loses: one MFMA per B fragment
 // built from 8 two-byte LDS reads, the dY tile re-staged once per (frame, channel) plane, element-wise global loads.
@@ -790,11 +1024,19 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     hipStream_t hs2 = static_cast<hipStream_t>(stream);
     const int nf = s->kt + 1;
     const int lds2 = nf * 3 * F2_PLANE + nf * 6 * 1024 + 8 * 16 * 2 * 4;
+    const int lds3 = 4 * 3 * F2_PLANE + nf * 6 * 1024 + 2 * 8 * 16 * 2 * 4;
+    const bool v3 = (sfk_tune().stem_v3 & 1) != 0 && stem_src_extent(s, y->n) < (1ll << 31);      // (v3 marks padding with voffset 2^31)
     const int tpairs = (k.t_log + 1) / 2;
     const int ppu = tpairs < 8 ? tpairs : 8;
     const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
     const int grid2 = nunits < 256 ? nunits : 256;
-    if (s->kt == 5) {
+    if (v3 && s->kt == 5) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v3_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+      hipLaunchKernelGGL((stem_fwd_v3_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds3, hs2, k, ppu, nunits);
+    } else if (v3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v3_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+      hipLaunchKernelGGL((stem_fwd_v3_kernel<3, 3>), dim3((unsigned)grid2), dim3(512), lds3, hs2, k, ppu, nunits);
+    } else if (s->kt == 5) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v2_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
       hipLaunchKernelGGL((stem_fwd_v2_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds2, hs2, k, ppu, nunits);
     } else {

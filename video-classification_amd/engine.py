@@ -149,6 +149,8 @@ class EngineOptions:
     trunk_priority: bool = True        # the trunk lane on a high-priority HIP stream (TrainStep)
     mfma_wgrad_trunk: bool = False     # MFMA-bound filter gradients on the pathway's own lane, directly behind their data gradient
     dist_wgrad_one_lane: bool = True   # world > 1: all filter gradients on ONE lane, the collective's stream is the fourth queue
+    lane_cus: str = ""                 # EXPERIMENT: CUs the side lanes may use, "fast,wgrad_slow,wgrad_fast" (0 / empty = all): the
+                                       # side streams are created with hipExtStreamCreateWithCUMask (eager schedule only)
     ablate_kinds: frozenset = frozenset()
 
     _ENV = {"SFK_FUSE_BNB": ("fuse_bn_bwd", "1"), "SFK_TAIL_DUAL": ("tail_dual", "!0"), "SFK_SHORTCUT_LANE": ("shortcut_lane", "s"),
@@ -157,7 +159,8 @@ class EngineOptions:
             "SFK_TAIL_MAXC": ("tail_max_c", "i"), "SFK_STEM_TAIL": ("fuse_stem_tail", "!0"), "SFK_TAIL_DG": ("fuse_tail_dg", "!0"),
             "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"),
             "SFK_SPLIT_ADAM": ("split_adam", "!0"), "SFK_TRUNK_PRIO": ("trunk_priority", "!0"),
-            "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0")}
+            "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0"),
+            "SFK_LANE_CUS": ("lane_cus", "s")}
 
     @classmethod
     def from_env(cls, env=None) -> "EngineOptions":
@@ -175,6 +178,26 @@ class EngineOptions:
         d = EngineOptions()
         return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)
                 if not f.name.startswith("_") and getattr(self, f.name) != getattr(d, f.name)}
+
+
+def _masked_stream(device, spec: int):
+    """EXPERIMENT (EngineOptions.lane_cus): a HIP stream whose kernels may only use some CUs.  spec = ncu (the first ncu mask
+    bits) or -ncu (the LAST ncu bits); the runtime deals mask bits round-robin over the 8 XCDs, so any contiguous run of bits
+    is spread evenly.  Wrapped as a torch ExternalStream; lives as long as the process."""
+    import ctypes as C
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    n = min(abs(spec), total)
+    bits = range(n) if spec > 0 else range(total - n, total)
+    words = (C.c_uint32 * ((total + 31) // 32))()
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    hip = C.CDLL("libamdhip64.so")            # the runtime torch already loaded (one instance per process)
+    st = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), words)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({spec}) failed: {rc}")
+    return torch.cuda.ExternalStream(st.value, device)
 
 
 class Engine:
@@ -1229,7 +1252,9 @@ class Engine:
         if not self.two_streams:
             return [main]
         if self._side is None:
-            self._side = [torch.cuda.Stream(self.device) for _ in range(self.NLANES - 1)]
+            cus = [int(v) for v in self.options.lane_cus.split(",")] if self.options.lane_cus else []
+            self._side = [_masked_stream(self.device, cus[i]) if i < len(cus) and cus[i] > 0 else torch.cuda.Stream(self.device)
+                          for i in range(self.NLANES - 1)]
         return [main] + self._side
 
     def _run_lanes(self, ops: "OpList", begin: int = 0, end: Optional[int] = None):
