@@ -493,6 +493,47 @@ def test_stem_conv_direct(hip, dtype, src_dtype, case):
     assert torch.equal(dwg.cpu().view(cout, kp)[pad], base.view(cout, kp)[pad])
 
 
+SLOW_STEM_CASES = [
+    # (n, t, h, w), frame index          stem_fwd_s3_kernel: canonical slow stem (3 -> 64, kt = 1), bf16, 16-byte output records
+    ((2, 5, 72, 64), None),               # odd clip length (a half pair), 36 x 32 output = 3 x 2 tiles with a ragged last row of tiles
+    ((1, 8, 40, 48), [0, 3, 7, 7, 2]),    # frames through PackPathway's index, 20 x 24 output (partial tiles both ways)
+    ((3, 4, 32, 32), None),               # whole tiles, two pairs = one unit
+]
+
+
+@pytest.mark.parametrize("case", SLOW_STEM_CASES, ids=["odd_t", "tindex", "whole"])
+def test_stem_conv_slow_register_filter_bf16(hip, case):
+    """the slow stem's forward on the register-filter kernel (sfk_tuning.stem_v3 bit 1): output into a channel slice with 16-byte
+    pixel records, BatchNorm partial sums, against the CPU restatement; the bytes beside the slice stay untouched."""
+    from video_classification_amd._lib import tuning
+    if not (tuning().stem_v3 & 2):
+        pytest.skip("the slow stem's register-filter kernel is off in this process (SFK_STEM3)")
+    (n, t, h, w), tidx = case
+    cin, cout, kt, dtype = 3, 64, 1, torch.bfloat16
+    gen = torch.Generator().manual_seed(29 + h)
+    emu = EmuBackend()
+    clip = mk((n, cin, t, h, w), dtype, gen)
+    ti_c = None if tidx is None else torch.tensor(tidx, dtype=torch.int32)
+    ti_g = None if tidx is None else ti_c.to(DEV)
+    t_out = t if tidx is None else len(tidx)
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    kp = stem_kp(cin, kt)
+    wref = torch.randn(cout, cin, kt, 7, 7, generator=gen) * (cin * kt * 49) ** -0.5
+    wl = torch.nn.functional.pad(wref.permute(0, 2, 1, 3, 4), (0, 1)).reshape(cout, kt * cin * 56)
+    wl = torch.nn.functional.pad(wl, (0, kp - wl.shape[1])).reshape(-1).to(dtype)
+    yc, yg = fmap_pair(n, cout, t_out, ho, wo, dtype, gen, ld=cout + 8, c_off=8, fill=2.0)
+    sc_, sg_ = StemSrc(clip, ti_c, kt), StemSrc(clip.to(DEV), ti_g, kt)
+    mt = hip.stem_conv_tiles(sg_, yg)
+    stc, stg = torch.zeros(mt * cout * 2), torch.full((mt * cout * 2,), float("nan"), device=DEV)
+    emu.stem_conv_fwd(sc_, wl, yc, stc)(0)
+    hip.stem_conv_fwd(sg_, wl.to(DEV), yg, stg)(stream())
+    torch.cuda.synchronize()
+    assert rel_err(yg.view5().float().cpu(), yc.view5().float()) < TOL[dtype]
+    assert torch.all(yg.buf.cpu().float().view(-1, cout + 8)[:, :8] == 2.0)
+    assert torch.isfinite(stg).all()
+    assert rel_err(stg.cpu().view(mt, cout, 2).sum(0), stc.view(mt, cout, 2).sum(0)) < 1e-4   # (the restatement's rows are not tiles)
+
+
 @pytest.mark.parametrize("c,nparts", [(8, 50176), (256, 3136), (80, 129), (2048, 300), (64, 128)],
                          ids=lambda v: str(v))
 def test_batchnorm_partial_fold_two_level(hip, c, nparts):

@@ -202,7 +202,7 @@ extern "C" int sfk_fill_zero(void* p, size_t bytes, sfk_stream_t stream) {
 
 // ------------------------------------------------------------------ tuning table (sfk_init)
 namespace {
-constexpr sfk_tuning kDefaults = {(uint32_t)sizeof(sfk_tuning), 5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 512, 0, 48, 1, 16, 1, 3, 1};
+constexpr sfk_tuning kDefaults = {(uint32_t)sizeof(sfk_tuning), 5, 0, 1, 192, 256, 1, 7, 1024, 0, 48, 150, 1, 1ll << 20, 3, 512, 0, 48, 1, 16, 1, 3, 3};
 sfk_tuning g_tuning = kDefaults;
 bool g_tuning_set = false;
 }  // namespace

@@ -618,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
   char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
   char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
   float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [2][8 waves][16 rows][2]
+  int* fidx = reinterpret_cast<int*>(red + 2 * 8 * 16 * 2);       // [32] physical frame of the unit's logical frames (-1: zeros)
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   bf16_t* yp = static_cast<bf16_t*>(k.y);
@@ -673,8 +674,8 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
     x_loc[i] = fr * SLOT + ci * F2_PLANE + (rr / 6) * F2_PITCH + (rr % 6) * 16;
   }
   uint32_t xv[3];                                                // voffsets of the current unit
-  uint4 xr[3];
-  int n = 0, ho0 = 0, wo0 = 0;
+  uint4 xra[3], xrb[3];                                          // two pairs in flight: a pair is fetched TWO iterations ahead
+  int n = 0, ho0 = 0, wo0 = 0, fbase = 0;                         // fbase: logical frame of fidx[0]
   const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
   const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
   auto unit_offsets = [&]() {
@@ -685,15 +686,13 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
       xv[i] = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
     }
   };
-  auto fetch = [&](int F0) {        // frames F0, F0 + 1 (logical)
+  auto fetch = [&](uint4 (&xr)[3], int F0) __attribute__((always_inline)) {        // frames F0, F0 + 1 (logical)
     uint32_t so[2];
     bool fok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int F = F0 + u;
-      int f = (F >= 0 && F < k.t_log) ? F : -1;
-      if (f >= 0 && k.t_index) f = k.t_index[f];
-      fok[u] = f >= 0 && f < k.t_in;
+      const int f = __builtin_amdgcn_readfirstlane(fidx[F0 + u - fbase]);      // (resolved once per unit: a frame-index load
+      fok[u] = f >= 0;                                                          // here would drain the loads in flight)
       so[u] = fok[u] ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f * k.st) * 2) : 0u;
     }
     const int u2 = wave >> 2;                                    // slot 2's frame (wave-uniform)
@@ -704,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
     xr[1] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
     xr[2] = make_uint4(v2[0], v2[1], v2[2], v2[3]);
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](const uint4 (&xr)[3], int buf) __attribute__((always_inline)) {
     *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[0]) = xr[0];
     *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[1]) = xr[1];
     if (x_row[2] >= 0) *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[2]) = xr[2];
@@ -723,16 +722,25 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
     ho0 = th * TS; wo0 = tw * TS;
     const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);
     unit_offsets();
-    __syncthreads();                                   // the previous unit's patch reads are done
-    fetch(2 * (p0 - 1));
-    stage(0);
+    fbase = 2 * (p0 - 1);
+    if (tid < 2 * (p1 - p0 + 2)) {                     // the unit's logical frames 2 (p0 - 1) .. 2 p1 + 1 -> physical frames
+      const int F = fbase + tid;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
+    }
+    __syncthreads();                                   // the previous unit's patch reads are done; fidx is visible
+    fetch(xra, 2 * (p0 - 1));
+    stage(xra, 0);
+    fetch(xrb, 2 * p0);
     __syncthreads();
     f32x4 acc[3][2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int cur = 0;
-    for (int m = p0 - 1; m <= p1; ++m) {
-      if (m < p1 && SFK_STEM_EXP != 3) fetch(2 * (m + 1));                  // the next input pair flies during this pair's MFMAs
+    // one input pair: fetch pair m + 2 into xf, multiply pair m out of buffer cur, store output pair m - 1, stage pair m + 1 (in
+    // xs since the previous iteration) into the other buffer
+    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[3], const uint4 (&xs)[3]) __attribute__((always_inline)) {
+      if (m + 2 <= p1 && SFK_STEM_EXP != 3) fetch(xf, 2 * (m + 2));
       const bool on[3] = {m - 1 >= p0, m >= p0 && m < p1, m + 1 < p1};      // is output pair m - 1 + r inside this unit?
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      if (m < p1 && SFK_STEM_EXP != 3) stage(cur ^ 1);
+      if (m < p1 && SFK_STEM_EXP != 3) stage(xs, cur ^ 1);
       __syncthreads();                                 // this pair's patch reads are done, the next pair is staged, red is complete
       if (on[0] && k.stats && tid < 16) {
         const int sjt = tid >> 3, sco = tid & 7, sto = to0 + sjt;
@@ -811,7 +819,240 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int 
           k.stats[(trow * k.cout + sco) * 2 + 1] = a2;
         }
       }
-      cur ^= 1;
+    };
+    for (int m = p0 - 1;;) {
+      pair_iter(m, 0, xra, xrb);
+      if (++m > p1) break;
+      pair_iter(m, 1, xrb, xra);
+      if (++m > p1) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward, slow stem (kt = 1, 64 channels)
+// The canonical slow stem through stem_fwd_kernel stages its patch element by element (18 two-byte loads in flight per thread),
+// re-reads the filter from LDS every K-step, reduces its statistics with 128 ds_bpermute shuffles per tile and stores 8 bytes
+// per lane: 300 us alone for 32 us of MFMAs and 61 us of HBM traffic.  This kernel is stem_fwd_v3_kernel's machinery with the
+// rows of the A fragments = 16 output channels (4 fragments, no temporal window): two frames per 16-byte-chunk fetch, two
+// fetches ahead, the 24 filter fragments in registers, one pixel run per FOUR MFMAs, DPP row sums, v_permlane16_swap between
+// channel fragments so that a lane stores 16 bytes (8 consecutive channels of a pixel).
+__device__ __forceinline__ void stem_swap16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int pairs_per_unit, int nunits) {
+  constexpr int SLOT = CIN * F2_PLANE;
+  constexpr int CPF = CIN * 2, NCF = 4, NCH = NCF * CPF;
+  constexpr int FRAME_CHUNKS = CIN * F2_PR * 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
+  char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [2 parities][2 frames][8 waves][64 co][2]
+  int* fidx = reinterpret_cast<int*>(red + 2 * 2 * 8 * 64 * 2);  // [32]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16_t* yp = static_cast<bf16_t*>(k.y);
+  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
+  const int perm_g = ((g & 1) << 1) | (g >> 1);                  // {0,2,1,3}
+
+  // ---- A matrix: amat[chunk cf*CPF + c6][row][k = 8g + k'] = w[co = 16 cf + row][ci = c6>>1][kh][k'-1]
+  {
+    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
+    for (int e = tid; e < NCH * 64; e += 512) {
+      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
+      const int cf = ch / CPF, c6 = ch % CPF;
+      const int co = 16 * cf + row;
+      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+      if (co < k.cout && kh < KH) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + (ci * KH + kh) * 8);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
+      }
+      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
+    }
+  }
+  __syncthreads();
+  bf16x8 afr[NCH];
+  {
+    const int a_lane = a_off(l15, g);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
+      asm volatile("" : "+v"(afr[ch]));
+    }
+  }
+
+  // ---- staging: as stem_fwd_v3_kernel
+  static_assert(FRAME_CHUNKS > 512 && FRAME_CHUNKS <= 768, "three single-frame loads per thread cover a pair");
+  int x_row[3], x_col[3], x_chan[3], x_loc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = i < 2 ? tid : 512 + (tid & 255);
+    const int fr = i < 2 ? i : tid >> 8;
+    const int ci = e / (F2_PR * 6), rr = e % (F2_PR * 6);
+    x_row[i] = e < FRAME_CHUNKS ? rr / 6 : -1000000;
+    x_col[i] = 8 * (rr % 6);
+    x_chan[i] = (int)(ci * k.sc * 2);
+    x_loc[i] = fr * SLOT + ci * F2_PLANE + (rr / 6) * F2_PITCH + (rr % 6) * 16;
+  }
+  uint32_t xv[3];
+  uint4 xra[3], xrb[3];
+  int n = 0, ho0 = 0, wo0 = 0, fbase = 0;
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
+  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
+  auto unit_offsets = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int hi = 2 * ho0 - 3 + x_row[i], wi = 2 * wo0 - 8 + x_col[i];
+      const bool ok = (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      xv[i] = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
+    }
+  };
+  auto fetch = [&](uint4 (&xr)[3], int F0) __attribute__((always_inline)) {
+    uint32_t so[2];
+    bool fok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = __builtin_amdgcn_readfirstlane(fidx[F0 + u - fbase]);
+      fok[u] = f >= 0;
+      so[u] = fok[u] ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f * k.st) * 2) : 0u;
+    }
+    const int u2 = wave >> 2;
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(fok[0] ? srs : srs0, (int)xv[0], (int)so[0], 0);
+    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(fok[1] ? srs : srs0, (int)xv[1], (int)so[1], 0);
+    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128((u2 ? fok[1] : fok[0]) ? srs : srs0, (int)xv[2], (int)(u2 ? so[1] : so[0]), 0);
+    xr[0] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+    xr[1] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+    xr[2] = make_uint4(v2[0], v2[1], v2[2], v2[3]);
+  };
+  auto stage = [&](const uint4 (&xr)[3], int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[0]) = xr[0];
+    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[1]) = xr[1];
+    if (x_row[2] >= 0) *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[2]) = xr[2];
+  };
+
+  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
+  const int tpairs = (k.t_log + 1) / 2;
+  const int tchunks = (tpairs + pairs_per_unit - 1) / pairs_per_unit;
+
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int tc = unit % tchunks;
+    int tile = unit / tchunks, th, tw;
+    tw = tile % k.tiles_w; tile /= k.tiles_w;
+    th = tile % k.tiles_h;
+    n = tile / k.tiles_h;
+    ho0 = th * TS; wo0 = tw * TS;
+    const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);      // input = output pairs p0 .. p1 - 1
+    unit_offsets();
+    fbase = 2 * p0;
+    if (tid < 2 * (p1 - p0 + 1)) {
+      const int F = fbase + tid;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
+    }
+    __syncthreads();                                   // the previous unit's patch reads are done; fidx is visible
+    fetch(xra, 2 * p0);
+    stage(xra, 0);
+    if (p0 + 1 < p1) fetch(xrb, 2 * (p0 + 1));
+    __syncthreads();
+    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[3], const uint4 (&xs)[3]) __attribute__((always_inline)) {
+      if (m + 2 < p1) fetch(xf, 2 * (m + 2));
+      float* redp = red + (m & 1) * (2 * 8 * 64 * 2);
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int to = 2 * m + par;
+        if (to >= k.t_out) continue;                   // odd clip length (wave-uniform)
+        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
+        f32x4 acc[NCF][2];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[cf][0] = acc[cf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c6 = 0; c6 < CPF; ++c6) {
+          bf16x8 bv[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * F2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
+            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
+            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
+          }
+#pragma unroll
+          for (int cf = 0; cf < NCF; ++cf) {
+            acc[cf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[0], acc[cf][0], 0, 0, 0);
+            acc[cf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[1], acc[cf][1], 0, 0, 0);
+          }
+        }
+        // ---- epilogue of output frame `to`: lane holds channels 16 cf + 4 g + r of pixel (2 wave + j, l15)
+        const int wo = wo0 + l15;
+        float s1[NCF][4], s2[NCF][4];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s1[cf][r] = s2[cf][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ho = ho0 + 2 * wave + j;
+          const bool pok = ho < k.ho && wo < k.wo;
+          if (pok) {
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s1[cf][r] += acc[cf][j][r]; s2[cf][r] += acc[cf][j][r] * acc[cf][j][r]; }
+          }
+          bf16_t* pix = yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff;
+#pragma unroll
+          for (int cp = 0; cp < NCF; cp += 2) {        // fragments cp, cp + 1 -> 8 consecutive channels per lane
+            float v[8] = {acc[cp][j][0], acc[cp][j][1], acc[cp][j][2], acc[cp][j][3],
+                          acc[cp + 1][j][0], acc[cp + 1][j][1], acc[cp + 1][j][2], acc[cp + 1][j][3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stem_swap16(v[e], v[4 + e]);
+            const int co = 16 * cp + 16 * (g & 1) + 8 * (g >> 1);
+            if (pok && co < k.cout) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+              *reinterpret_cast<bf16x8*>(pix + co) = o;
+            }
+          }
+        }
+        if (k.stats) {
+#pragma unroll
+          for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = stem_row16_sum(s1[cf][r]), c = stem_row16_sum(s2[cf][r]);
+              if (l15 == 15) {
+                redp[((par * 8 + wave) * 64 + 16 * cf + 4 * g + r) * 2 + 0] = a;
+                redp[((par * 8 + wave) * 64 + 16 * cf + 4 * g + r) * 2 + 1] = c;
+              }
+            }
+        }
+      }
+      if (m + 1 < p1) stage(xs, cur ^ 1);
+      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged, red is complete
+      if (k.stats && tid < 128) {
+        const int par = tid >> 6, co = tid & 63, to = 2 * m + par;
+        if (to < k.t_out && co < k.cout) {
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int w_ = 0; w_ < 8; ++w_) { a1 += redp[((par * 8 + w_) * 64 + co) * 2]; a2 += redp[((par * 8 + w_) * 64 + co) * 2 + 1]; }
+          const int64_t trow = (((int64_t)n * k.t_out + to) * k.tiles_h + th) * k.tiles_w + tw;
+          k.stats[(trow * k.cout + co) * 2 + 0] = a1;
+          k.stats[(trow * k.cout + co) * 2 + 1] = a2;
+        }
+      }
+    };
+    for (int m = p0;;) {
+      pair_iter(m, 0, xra, xrb);
+      if (++m >= p1) break;
+      pair_iter(m, 1, xrb, xra);
+      if (++m >= p1) break;
     }
   }
 }
@@ -1024,7 +1265,7 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     hipStream_t hs2 = static_cast<hipStream_t>(stream);
     const int nf = s->kt + 1;
     const int lds2 = nf * 3 * F2_PLANE + nf * 6 * 1024 + 8 * 16 * 2 * 4;
-    const int lds3 = 4 * 3 * F2_PLANE + nf * 6 * 1024 + 2 * 8 * 16 * 2 * 4;
+    const int lds3 = 4 * 3 * F2_PLANE + nf * 6 * 1024 + 2 * 8 * 16 * 2 * 4 + 32 * 4;
     const bool v3 = (sfk_tune().stem_v3 & 1) != 0 && stem_src_extent(s, y->n) < (1ll << 31);      // (v3 marks padding with voffset 2^31)
     const int tpairs = (k.t_log + 1) / 2;
     const int ppu = tpairs < 8 ? tpairs : 8;
@@ -1043,6 +1284,23 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v2_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
       hipLaunchKernelGGL((stem_fwd_v2_kernel<3, 3>), dim3((unsigned)grid2), dim3(512), lds2, hs2, k, ppu, nunits);
     }
+    SFK_CHECK_LAUNCH();
+    return SFK_OK;
+  }
+  // canonical slow stem geometry in bf16: the register-filter kernel above
+  if ((sfk_tune().stem_v3 & 2) && y->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && s->kt == 1 && y->c == 64 &&
+      s->sw == 1 && (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15) &&
+      !(y->ld % 8) && !(y->c_off % 8) && stem_src_extent(s, y->n) < (1ll << 31)) {
+    k.src_bytes = (uint32_t)stem_src_extent(s, y->n);
+    k.y_bytes = 0;
+    hipStream_t hs3 = static_cast<hipStream_t>(stream);
+    const int lds = 4 * 3 * F2_PLANE + 24 * 1024 + 2 * 2 * 8 * 64 * 2 * 4 + 32 * 4;
+    const int tpairs = (k.t_log + 1) / 2;
+    const int ppu = tpairs < 2 ? tpairs : 2;
+    const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
+    const int grid = nunits < 256 ? nunits : 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((stem_fwd_s3_kernel<3>), dim3((unsigned)grid), dim3(512), lds, hs3, k, ppu, nunits);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
