@@ -850,8 +850,8 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
   char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
-  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [2 parities][2 frames][8 waves][64 co][2]
-  int* fidx = reinterpret_cast<int*>(red + 2 * 2 * 8 * 64 * 2);  // [32]
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [8 waves][64 co][2]
+  int* fidx = reinterpret_cast<int*>(red + 8 * 64 * 2);          // [32]
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   bf16_t* yp = static_cast<bf16_t*>(k.y);
@@ -962,9 +962,16 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int 
     stage(xra, 0);
     if (p0 + 1 < p1) fetch(xrb, 2 * (p0 + 1));
     __syncthreads();
+    // BatchNorm partial sums of the WHOLE unit (all its frames) in one statistics row -- the row of its first frame's tile; the
+    // rows of the other frames get zeros (the consumer folds all rows).  Per frame that is 64 multiply-adds instead of 64 + 128
+    // DPP adds: the epilogue's vector instructions, not the MFMAs, bound the first version (280 against 48 x 16 cycles).
+    float s1[NCF][4], s2[NCF][4];
+#pragma unroll
+    for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1[cf][r] = s2[cf][r] = 0.f;
     auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[3], const uint4 (&xs)[3]) __attribute__((always_inline)) {
       if (m + 2 < p1) fetch(xf, 2 * (m + 2));
-      float* redp = red + (m & 1) * (2 * 8 * 64 * 2);
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
         const int to = 2 * m + par;
@@ -990,11 +997,6 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int 
         }
         // ---- epilogue of output frame `to`: lane holds channels 16 cf + 4 g + r of pixel (2 wave + j, l15)
         const int wo = wo0 + l15;
-        float s1[NCF][4], s2[NCF][4];
-#pragma unroll
-        for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s1[cf][r] = s2[cf][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int ho = ho0 + 2 * wave + j;
@@ -1021,38 +1023,40 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int 
             }
           }
         }
-        if (k.stats) {
-#pragma unroll
-          for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float a = stem_row16_sum(s1[cf][r]), c = stem_row16_sum(s2[cf][r]);
-              if (l15 == 15) {
-                redp[((par * 8 + wave) * 64 + 16 * cf + 4 * g + r) * 2 + 0] = a;
-                redp[((par * 8 + wave) * 64 + 16 * cf + 4 * g + r) * 2 + 1] = c;
-              }
-            }
-        }
       }
       if (m + 1 < p1) stage(xs, cur ^ 1);
-      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged, red is complete
-      if (k.stats && tid < 128) {
-        const int par = tid >> 6, co = tid & 63, to = 2 * m + par;
-        if (to < k.t_out && co < k.cout) {
-          float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-          for (int w_ = 0; w_ < 8; ++w_) { a1 += redp[((par * 8 + w_) * 64 + co) * 2]; a2 += redp[((par * 8 + w_) * 64 + co) * 2 + 1]; }
-          const int64_t trow = (((int64_t)n * k.t_out + to) * k.tiles_h + th) * k.tiles_w + tw;
-          k.stats[(trow * k.cout + co) * 2 + 0] = a1;
-          k.stats[(trow * k.cout + co) * 2 + 1] = a2;
-        }
-      }
+      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged
     };
     for (int m = p0;;) {
       pair_iter(m, 0, xra, xrb);
       if (++m >= p1) break;
       pair_iter(m, 1, xrb, xra);
       if (++m >= p1) break;
+    }
+    if (k.stats) {
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = stem_row16_sum(s1[cf][r]), c = stem_row16_sum(s2[cf][r]);
+          if (l15 == 15) {
+            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 0] = a;
+            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 1] = c;
+          }
+        }
+      __syncthreads();
+      const int nfr = min(2 * p1, k.t_out) - 2 * p0;       // output frames of this unit
+      for (int e = tid; e < nfr * k.cout; e += 512) {
+        const int fr = e / k.cout, co = e - fr * k.cout;
+        float a1 = 0.f, a2 = 0.f;
+        if (fr == 0) {
+#pragma unroll
+          for (int w_ = 0; w_ < 8; ++w_) { a1 += red[(w_ * 64 + co) * 2]; a2 += red[(w_ * 64 + co) * 2 + 1]; }
+        }
+        const int64_t trow = (((int64_t)n * k.t_out + 2 * p0 + fr) * k.tiles_h + th) * k.tiles_w + tw;
+        k.stats[(trow * k.cout + co) * 2 + 0] = a1;
+        k.stats[(trow * k.cout + co) * 2 + 1] = a2;
+      }
     }
   }
 }
@@ -1294,7 +1298,7 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     k.src_bytes = (uint32_t)stem_src_extent(s, y->n);
     k.y_bytes = 0;
     hipStream_t hs3 = static_cast<hipStream_t>(stream);
-    const int lds = 4 * 3 * F2_PLANE + 24 * 1024 + 2 * 2 * 8 * 64 * 2 * 4 + 32 * 4;
+    const int lds = 4 * 3 * F2_PLANE + 24 * 1024 + 8 * 64 * 2 * 4 + 32 * 4;
     const int tpairs = (k.t_log + 1) / 2;
     const int ppu = tpairs < 2 ? tpairs : 2;
     const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
