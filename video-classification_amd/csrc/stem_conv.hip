@@ -1109,28 +1109,41 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_v2_kernel(const StemK k) {
   uint4 xr[NXC], dr[NDC];
   const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
   const __amdgpu_buffer_rsrc_t yrs = sfk_make_rsrc(k.y, k.y_bytes);
+  // Addresses: the per-thread part (channel / patch row / chunk, or the pixel of the dY tile) is a 32-bit voffset, the
+  // (clip, frame) base rides the instruction's scalar offset (not range-checked: an out-of-range voffset still reads zeros);
+  // a frame outside the clip reads through a zero-sized resource.  The first version built a 64-bit address per chunk: ~150
+  // vector instructions per item and wave, as many issue cycles as the item's 72 MFMAs.
+  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
+  const __amdgpu_buffer_rsrc_t yrs0 = sfk_make_rsrc(k.y, 0);
+  int x_chan[NXC];
+#pragma unroll
+  for (int i = 0; i < NXC; ++i) x_chan[i] = x_ci[i] < 0 ? 0 : (int)(x_ci[i] * k.sc * 2);
   auto fetch = [&](int item) {
     int n, tf, ho0, wo0;
     tile_coords(k, item, n, tf, ho0, wo0);
-    int frame = k.t_index ? k.t_index[tf] : tf;
+    int frame = k.t_index ? __builtin_amdgcn_readfirstlane(k.t_index[tf]) : tf;
     const bool fok = frame >= 0 && frame < k.t_in;
-    if (!fok) frame = 0;
+    const uint32_t xso = fok ? (uint32_t)(((int64_t)n * k.sn + (int64_t)frame * k.st) * 2) : 0u;
     // branch-free buffer loads (out-of-range offset -> zeros): all of an item's loads are issued in one batch
 #pragma unroll
     for (int i = 0; i < NXC; ++i) {
       const int hi = 2 * ho0 - 3 + x_r[i], wi = 2 * wo0 - 8 + 8 * x_j[i];
-      const bool ok = fok && x_ci[i] >= 0 && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
-      const int64_t off = (int64_t)n * k.sn + (int64_t)(x_ci[i] < 0 ? 0 : x_ci[i]) * k.sc + (int64_t)frame * k.st + (int64_t)hi * k.sh + wi;
-      xr[i] = sfk_buffer_load16(srs, ok ? (uint32_t)(off * 2) : SFK_OOB);
+      const bool ok = x_ci[i] >= 0 && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      const uint32_t vo = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(fok ? srs : srs0, (int)vo, (int)xso, 0);
+      xr[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
     const int ho = ho0 + (tid >> 4), wo = wo0 + (tid & 15);
     const bool pok = ho < k.ho && wo < k.wo;
+    const uint32_t yvo = pok ? (uint32_t)(((ho * k.wo + wo) * k.yld + k.yoff) * 2) : 0x80000000u;
+    const int64_t fstride = (int64_t)k.ho * k.wo * k.yld * 2;          // bytes per output frame
 #pragma unroll
     for (int f = 0; f < NDC; ++f) {
       const int to = tf + k.pt - f;
-      const bool ok = f < k.kt && pok && to >= 0 && to < k.t_out;
-      const int64_t off = ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff;
-      dr[f] = sfk_buffer_load16(yrs, ok ? (uint32_t)(off * 2) : SFK_OOB);
+      const bool ok = f < k.kt && to >= 0 && to < k.t_out;               // (wave-uniform)
+      const uint32_t yso = ok ? (uint32_t)(((int64_t)n * k.t_out + to) * fstride) : 0u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ok ? yrs : yrs0, (int)yvo, (int)yso, 0);
+      dr[f] = make_uint4(v[0], v[1], v[2], v[3]);
     }
   };
   auto stage = [&]() {
@@ -1351,7 +1364,7 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
   // canonical fast stem geometry in bf16 with 16-byte addressable rows: the input-frame-stationary kernel
   if (dy->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && s->kt <= 5 && dy->c <= 8 && s->sw == 1 &&
       (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15) &&
-      stem_src_extent(s, dy->n) < (1ll << 32) - 64 && sfk_fmap_bytes(dy) < (1ll << 32) - 64) {
+      stem_src_extent(s, dy->n) < (1ll << 31) && sfk_fmap_bytes(dy) < (1ll << 31)) {      // (padding = voffset 2^31)
     k.src_bytes = (uint32_t)stem_src_extent(s, dy->n);
     k.y_bytes = (uint32_t)sfk_fmap_bytes(dy);
     int blocks = 256 * 3;                       // 3 resident workgroups per CU (LDS 44 KB each)
