@@ -1061,6 +1061,405 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, half tiles (256 threads)
+// stem_fwd_v3_kernel / stem_fwd_s3_kernel are 512-thread workgroups with ~235 registers per lane: ONE workgroup owns a CU's whole
+// register file, so (a) its phases -- fetch, MFMAs, epilogue, barrier -- run strictly one after the other (measured: the parts
+// add up), and (b) while one stem's persistent workgroups hold the CUs nothing else becomes resident: the two stems ran one after
+// the other and the slow pathway's small kernels waited (bn_finalize 139 us in the step's timeline).  The kernels below are the
+// same machines on HALF tiles (16 x 8 output pixels) with 4 waves: two workgroups -- of either kernel -- share a CU, one
+// multiplies while the other fetches / stores.  BatchNorm partial sums: a workgroup adds up its whole unit and writes ONE
+// statistics row; the rows of the unit's other frames are zeros (the consumer folds all rows).  The two halves of a 16 x 16
+// statistics tile write disjoint rows: half h the frames of parity h (a unit has at least two frames).
+constexpr int H2_ROWS = 8;                      // output rows of a half tile
+constexpr int H2_PR = 2 * H2_ROWS + 6;          // 22 patch rows (21 + the row the padded kh = 7 reads)
+constexpr int H2_PLANE = H2_PR * F2_PITCH;      // 2112 B
+
+// staging of input PAIRS for a 256-thread workgroup: four 16-byte chunks per thread and pair (slot s: frame s & 1, chunk
+// tid + 256 (s >> 1) of the frame's CIN x 22 x 6), the (clip, frame) base on the scalar offset, padding = voffset 2^31
+template <int CIN>
+struct H2Stage {
+  static constexpr int SLOT = CIN * H2_PLANE, FC = CIN * H2_PR * 6;
+  static_assert(FC > 256 && FC <= 512, "two loads per thread and frame");
+  uint32_t desc[2];      // per chunk index (s >> 1): bits 0..15 byte offset inside the frame patch, 16..21 row, 22..24 chunk, 31 unused
+  int chan[2];
+  uint32_t xv[2];        // voffsets of the current unit
+  __device__ __forceinline__ void init(const StemK& k, int tid) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = tid + 256 * h;
+      const int ci = e / (H2_PR * 6), rr = e % (H2_PR * 6);
+      const int row = rr / 6, jc = rr % 6;
+      desc[h] = (uint32_t)(ci * H2_PLANE + row * F2_PITCH + jc * 16) | (uint32_t)row << 16 | (uint32_t)jc << 22 | (uint32_t)(e >= FC) << 31;
+      chan[h] = (int)(ci * k.sc * 2);
+    }
+  }
+  __device__ __forceinline__ void unit(const StemK& k, int ho0, int wo0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int hi = 2 * ho0 - 3 + (int)((desc[h] >> 16) & 63), wi = 2 * wo0 - 8 + 8 * (int)((desc[h] >> 22) & 7);
+      const bool ok = !(desc[h] >> 31) && (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
+      xv[h] = ok ? (uint32_t)(chan[h] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
+    }
+  }
+  // frames f0 / f1 = physical frames (-1: zeros) of the pair
+  __device__ __forceinline__ void fetch(const StemK& k, uint4 (&xr)[4], __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs0, int n, int f0,
+                                        int f1) const {
+    const uint32_t so0 = f0 >= 0 ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f0 * k.st) * 2) : 0u;
+    const uint32_t so1 = f1 >= 0 ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f1 * k.st) * 2) : 0u;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const bool second = s_ & 1;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128((second ? f1 : f0) >= 0 ? rs : rs0, (int)xv[s_ >> 1], (int)(second ? so1 : so0), 0);
+      xr[s_] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __device__ __forceinline__ void stage(char* pair_buf, const uint4 (&xr)[4]) const {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+      if (!(desc[s_ >> 1] >> 31)) *reinterpret_cast<uint4*>(pair_buf + (s_ & 1) * SLOT + (desc[s_ >> 1] & 0xFFFFu)) = xr[s_];
+  }
+};
+
+// unit decomposition shared by the two kernels: (clip, half tile, chunk of pairs); the last chunk takes a trailing half pair
+struct H2Unit {
+  int n, th2, tw, p0, p1;
+  __device__ __forceinline__ void set(const StemK& k, int unit, int ppu, int tchunks, int tiles_h2, int tpairs) {
+    const int tc = unit % tchunks;
+    int tile = unit / tchunks;
+    tw = tile % k.tiles_w; tile /= k.tiles_w;
+    th2 = tile % tiles_h2;
+    n = tile / tiles_h2;
+    p0 = tc * ppu;
+    p1 = tc == tchunks - 1 ? tpairs : p0 + ppu;
+  }
+};
+
+// fast stem: stem_fwd_v3_kernel on half tiles
+template <int CIN, int KT>
+__global__ __launch_bounds__(256, 2) void stem_fwd_v4_kernel(const StemK k, int pairs_per_unit, int nunits, int tchunks) {
+  constexpr int NF = KT + 1, PT = KT / 2;
+  constexpr int SLOT = CIN * H2_PLANE;
+  constexpr int CPF = CIN * 2;
+  constexpr int NCH = NF * CPF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][22][96 B]
+  char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [4 waves][16 rows][2]
+  int* fidx = reinterpret_cast<int*>(red + 4 * 16 * 2);          // [32]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16_t* yp = static_cast<bf16_t*>(k.y);
+  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
+  const int perm_g = ((g & 1) << 1) | (g >> 1);
+  {
+    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
+    for (int e = tid; e < NCH * 64; e += 256) {
+      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
+      const int fp = ch / CPF, c6 = ch % CPF;
+      const int jt = row >> 3, co = row & 7, f = fp - jt;
+      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+      if (f >= 0 && f < KT && co < k.cout && kh < KH) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + ((f * CIN + ci) * KH + kh) * 8);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
+      }
+      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
+    }
+  }
+  __syncthreads();
+  bf16x8 afr[NCH];
+  {
+    const int a_lane = a_off(l15, g);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
+      asm volatile("" : "+v"(afr[ch]));
+    }
+  }
+  H2Stage<CIN> stg;
+  stg.init(k, tid);
+  uint4 xra[4], xrb[4];
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
+  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
+  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
+  const int tpairs = (k.t_log + 1) / 2;
+  const int tiles_h2 = (k.ho + H2_ROWS - 1) / H2_ROWS;
+  H2Unit u;
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    u.set(k, unit, pairs_per_unit, tchunks, tiles_h2, tpairs);
+    const int n = u.n, p0 = u.p0, p1 = u.p1;
+    const int ho0 = u.th2 * H2_ROWS, wo0 = u.tw * TS;
+    stg.unit(k, ho0, wo0);
+    const int fbase = 2 * (p0 - 1);
+    if (tid < 2 * (p1 - p0 + 2)) {
+      const int F = fbase + tid;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
+    }
+    __syncthreads();                                   // the previous unit's patch / red reads are done; fidx is visible
+    auto frame_of = [&](int F) { return __builtin_amdgcn_readfirstlane(fidx[F - fbase]); };
+    stg.fetch(k, xra, srs, srs0, n, frame_of(2 * (p0 - 1)), frame_of(2 * (p0 - 1) + 1));
+    stg.stage(pb, xra);
+    stg.fetch(k, xrb, srs, srs0, n, frame_of(2 * p0), frame_of(2 * p0 + 1));
+    __syncthreads();
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // the unit's sums of this lane's rows (jt, co)
+    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[4], const uint4 (&xs)[4]) __attribute__((always_inline)) {
+      if (m + 2 <= p1) stg.fetch(k, xf, srs, srs0, n, frame_of(2 * (m + 2)), frame_of(2 * (m + 2) + 1));
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int F = 2 * m + par;
+        if (F < 0 || F >= k.t_log) continue;           // temporal padding (wave-uniform)
+        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
+#pragma unroll
+        for (int c6 = 0; c6 < CPF; ++c6) {
+          bf16x8 bv[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * H2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
+            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
+            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int fp = par + 2 - 2 * r + PT;       // (pairs outside the unit are multiplied too and roll out unstored)
+            if (fp >= 0 && fp < NF) {
+              acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[0], acc[r][0], 0, 0, 0);
+              acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[1], acc[r][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // ---- output pair m - 1 is complete: lane holds rows 4g..4g+3 = (jt = g>>1, co = 4*(g&1) + r) of pixel (2*wave + j, l15)
+      if (m - 1 >= p0) {
+        const int jt = g >> 1, co0 = 4 * (g & 1), to = 2 * (m - 1) + jt;
+        const int wo = wo0 + l15;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ho = ho0 + 2 * wave + j;
+          if (to < k.t_out && ho < k.ho && wo < k.wo && co0 < k.cout) {
+            store4(yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + co0, acc[0][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] += acc[0][j][r]; s2[r] += acc[0][j][r] * acc[0][j][r]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      if (m < p1) stg.stage(pb + (cur ^ 1) * 2 * SLOT, xs);
+      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged
+    };
+    for (int m = p0 - 1;;) {
+      pair_iter(m, 0, xra, xrb);
+      if (++m > p1) break;
+      pair_iter(m, 1, xrb, xra);
+      if (++m > p1) break;
+    }
+    if (k.stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = stem_row16_sum(s1[r]), c = stem_row16_sum(s2[r]);
+        if (l15 == 15) {
+          red[(wave * 16 + 4 * g + r) * 2 + 0] = a;
+          red[(wave * 16 + 4 * g + r) * 2 + 1] = c;
+        }
+      }
+      __syncthreads();
+      const int half = u.th2 & 1, th = u.th2 >> 1;
+      const bool alone = (u.th2 | 1) >= tiles_h2;          // the statistics tile has no second half: all its rows are ours
+      const int nfr = min(2 * p1, k.t_out) - 2 * p0;       // output frames of this unit (>= 2)
+      for (int e = tid; e < nfr * k.cout; e += 256) {
+        const int fr = e / k.cout, co = e - fr * k.cout;
+        if (!alone && (fr & 1) != half) continue;            // the other half tile's rows
+        float a1 = 0.f, a2 = 0.f;
+        if (fr == half && co < 8) {
+#pragma unroll
+          for (int w_ = 0; w_ < 4; ++w_)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) { a1 += red[(w_ * 16 + jt * 8 + co) * 2]; a2 += red[(w_ * 16 + jt * 8 + co) * 2 + 1]; }
+        }
+        const int64_t trow = (((int64_t)n * k.t_out + 2 * p0 + fr) * k.tiles_h + th) * k.tiles_w + u.tw;
+        k.stats[(trow * k.cout + co) * 2 + 0] = a1;
+        k.stats[(trow * k.cout + co) * 2 + 1] = a2;
+      }
+    }
+  }
+}
+
+// slow stem: stem_fwd_s3_kernel on half tiles
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void stem_fwd_s4_kernel(const StemK k, int pairs_per_unit, int nunits, int tchunks) {
+  constexpr int SLOT = CIN * H2_PLANE;
+  constexpr int CPF = CIN * 2, NCF = 4, NCH = NCF * CPF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* pb = smem;
+  char* amat = smem + 4 * SLOT;
+  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [4 waves][64 co][2]
+  int* fidx = reinterpret_cast<int*>(red + 4 * 64 * 2);          // [32]
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16_t* yp = static_cast<bf16_t*>(k.y);
+  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
+  const int perm_g = ((g & 1) << 1) | (g >> 1);
+  {
+    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
+    for (int e = tid; e < NCH * 64; e += 256) {
+      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
+      const int cf = ch / CPF, c6 = ch % CPF;
+      const int co = 16 * cf + row;
+      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
+      if (co < k.cout && kh < KH) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + (ci * KH + kh) * 8);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
+      }
+      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
+    }
+  }
+  __syncthreads();
+  bf16x8 afr[NCH];
+  {
+    const int a_lane = a_off(l15, g);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
+      asm volatile("" : "+v"(afr[ch]));
+    }
+  }
+  H2Stage<CIN> stg;
+  stg.init(k, tid);
+  uint4 xra[4], xrb[4];
+  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
+  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
+  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
+  const int tpairs = (k.t_log + 1) / 2;
+  const int tiles_h2 = (k.ho + H2_ROWS - 1) / H2_ROWS;
+  H2Unit u;
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    u.set(k, unit, pairs_per_unit, tchunks, tiles_h2, tpairs);
+    const int n = u.n, p0 = u.p0, p1 = u.p1;                 // input = output pairs p0 .. p1 - 1
+    const int ho0 = u.th2 * H2_ROWS, wo0 = u.tw * TS;
+    stg.unit(k, ho0, wo0);
+    const int fbase = 2 * p0;
+    if (tid < 2 * (p1 - p0)) {
+      const int F = fbase + tid;
+      int f = (F >= 0 && F < k.t_log) ? F : -1;
+      if (f >= 0 && k.t_index) f = k.t_index[f];
+      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
+    }
+    __syncthreads();
+    auto frame_of = [&](int F) { return __builtin_amdgcn_readfirstlane(fidx[F - fbase]); };
+    stg.fetch(k, xra, srs, srs0, n, frame_of(2 * p0), frame_of(2 * p0 + 1));
+    stg.stage(pb, xra);
+    if (p0 + 1 < p1) stg.fetch(k, xrb, srs, srs0, n, frame_of(2 * (p0 + 1)), frame_of(2 * (p0 + 1) + 1));
+    __syncthreads();
+    float s1[NCF][4], s2[NCF][4];
+#pragma unroll
+    for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1[cf][r] = s2[cf][r] = 0.f;
+    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[4], const uint4 (&xs)[4]) __attribute__((always_inline)) {
+      if (m + 2 < p1) stg.fetch(k, xf, srs, srs0, n, frame_of(2 * (m + 2)), frame_of(2 * (m + 2) + 1));
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int to = 2 * m + par;
+        if (to >= k.t_out) continue;                   // odd clip length (wave-uniform)
+        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
+        f32x4 acc[NCF][2];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[cf][0] = acc[cf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c6 = 0; c6 < CPF; ++c6) {
+          bf16x8 bv[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * H2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
+            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
+            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
+          }
+#pragma unroll
+          for (int cf = 0; cf < NCF; ++cf) {
+            acc[cf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[0], acc[cf][0], 0, 0, 0);
+            acc[cf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[1], acc[cf][1], 0, 0, 0);
+          }
+        }
+        const int wo = wo0 + l15;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ho = ho0 + 2 * wave + j;
+          const bool pok = ho < k.ho && wo < k.wo;
+          if (pok) {
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s1[cf][r] += acc[cf][j][r]; s2[cf][r] += acc[cf][j][r] * acc[cf][j][r]; }
+          }
+          bf16_t* pix = yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff;
+#pragma unroll
+          for (int cp = 0; cp < NCF; cp += 2) {
+            float v[8] = {acc[cp][j][0], acc[cp][j][1], acc[cp][j][2], acc[cp][j][3],
+                          acc[cp + 1][j][0], acc[cp + 1][j][1], acc[cp + 1][j][2], acc[cp + 1][j][3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stem_swap16(v[e], v[4 + e]);
+            const int co = 16 * cp + 16 * (g & 1) + 8 * (g >> 1);
+            if (pok && co < k.cout) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+              *reinterpret_cast<bf16x8*>(pix + co) = o;
+            }
+          }
+        }
+      }
+      if (m + 1 < p1) stg.stage(pb + (cur ^ 1) * 2 * SLOT, xs);
+      __syncthreads();
+    };
+    for (int m = p0;;) {
+      pair_iter(m, 0, xra, xrb);
+      if (++m >= p1) break;
+      pair_iter(m, 1, xrb, xra);
+      if (++m >= p1) break;
+    }
+    if (k.stats) {
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = stem_row16_sum(s1[cf][r]), c = stem_row16_sum(s2[cf][r]);
+          if (l15 == 15) {
+            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 0] = a;
+            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 1] = c;
+          }
+        }
+      __syncthreads();
+      const int half = u.th2 & 1, th = u.th2 >> 1;
+      const bool alone = (u.th2 | 1) >= tiles_h2;
+      const int nfr = min(2 * p1, k.t_out) - 2 * p0;       // output frames of this unit (>= 2)
+      for (int e = tid; e < nfr * k.cout; e += 256) {
+        const int fr = e / k.cout, co = e - fr * k.cout;
+        if (!alone && (fr & 1) != half) continue;
+        float a1 = 0.f, a2 = 0.f;
+        if (fr == half) {
+#pragma unroll
+          for (int w_ = 0; w_ < 4; ++w_) { a1 += red[(w_ * 64 + co) * 2]; a2 += red[(w_ * 64 + co) * 2 + 1]; }
+        }
+        const int64_t trow = (((int64_t)n * k.t_out + 2 * p0 + fr) * k.tiles_h + th) * k.tiles_w + u.tw;
+        k.stats[(trow * k.cout + co) * 2 + 0] = a1;
+        k.stats[(trow * k.cout + co) * 2 + 1] = a2;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ filter gradient, v2
 // The canonical fast stem (5x7x7, 3 -> 8 channels) is where the generic kernel above loses: one MFMA per B fragment
 // built from 8 two-byte LDS reads, the dY tile re-staged once per (frame, channel) plane, element-wise global loads.
@@ -1288,7 +1687,19 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     const int ppu = tpairs < 8 ? tpairs : 8;
     const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
     const int grid2 = nunits < 256 ? nunits : 256;
-    if (v3 && s->kt == 5) {
+    if (v3 && (sfk_tune().stem_v3 & 4) && k.t_log >= 2) {        // half tiles: two workgroups per CU
+      const int nfull = k.t_log / 2, tch = nfull <= ppu ? 1 : (nfull + ppu - 1) / ppu;
+      const int nu = y->n * ((y->h + H2_ROWS - 1) / H2_ROWS) * k.tiles_w * tch;
+      const int grid4 = nu < 512 ? nu : 512;
+      const int lds4 = 4 * 3 * H2_PLANE + nf * 6 * 1024 + 4 * 16 * 2 * 4 + 32 * 4;
+      if (s->kt == 5) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v4_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        hipLaunchKernelGGL((stem_fwd_v4_kernel<3, 5>), dim3((unsigned)grid4), dim3(256), lds4, hs2, k, ppu, nu, tch);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v4_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        hipLaunchKernelGGL((stem_fwd_v4_kernel<3, 3>), dim3((unsigned)grid4), dim3(256), lds4, hs2, k, ppu, nu, tch);
+      }
+    } else if (v3 && s->kt == 5) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v3_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
       hipLaunchKernelGGL((stem_fwd_v3_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds3, hs2, k, ppu, nunits);
     } else if (v3) {
@@ -1316,6 +1727,16 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     const int ppu = tpairs < 2 ? tpairs : 2;
     const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
     const int grid = nunits < 256 ? nunits : 256;
+    if ((sfk_tune().stem_v3 & 8) && k.t_log >= 2) {              // half tiles: two workgroups per CU
+      const int nfull = k.t_log / 2, tch = nfull <= ppu ? 1 : (nfull + ppu - 1) / ppu;
+      const int nu = y->n * ((y->h + H2_ROWS - 1) / H2_ROWS) * k.tiles_w * tch;
+      const int grid4 = nu < 512 ? nu : 512;
+      const int lds4 = 4 * 3 * H2_PLANE + 24 * 1024 + 4 * 64 * 2 * 4 + 32 * 4;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+      hipLaunchKernelGGL((stem_fwd_s4_kernel<3>), dim3((unsigned)grid4), dim3(256), lds4, hs3, k, ppu, nu, tch);
+      SFK_CHECK_LAUNCH();
+      return SFK_OK;
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((stem_fwd_s3_kernel<3>), dim3((unsigned)grid), dim3(512), lds, hs3, k, ppu, nunits);
     SFK_CHECK_LAUNCH();
