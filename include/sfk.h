@@ -502,8 +502,9 @@ typedef struct {
                                          workspace: conv_wgrad_band.hip): bit 0: 64 -> 64 (1,3,3) over 56 x 56 frames (slow res2 conv_b);
                                          bit 1: 128 -> 128 over 28 x 28 (slow res3 conv_b)                                  */
   int32_t stem_v3;            /* 3:    bit 0: the input-frame-stationary forward of the canonical fast stem (filter in registers, one LDS
-                                         pixel run per three MFMAs: stem_fwd_v3_kernel); bit 1: the same machinery for the canonical
-                                         slow stem (kt = 1, 64 channels: stem_fwd_s3_kernel)                                 */
+                                         pixel run per three MFMAs, half tiles with two workgroups per CU: stem_fwd_v4_kernel);
+                                         bit 1: the same machinery for the canonical slow stem (kt = 1, 64 channels:
+                                         stem_fwd_s4_kernel)                                                               */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

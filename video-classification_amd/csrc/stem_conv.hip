@@ -11,10 +11,6 @@
 // index (PackPathway), as f32 or bf16.
 #include "sfk_common.h"
 
-#ifndef SFK_STEM_EXP
-#define SFK_STEM_EXP 0     // timing experiments on stem_fwd_v3_kernel (results wrong): 1 no MFMAs, 2 no epilogue, 3 no per-pair fetch / stage, 4 no pixel-run reads
-#endif
-
 namespace {
 
 constexpr int TS = 16;            // output tile edge (pixels)
@@ -586,6 +582,26 @@ __global__ __launch_bounds__(512, 2) void stem_fwd_v2_kernel(const StemK k, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, v3 (the design; the kernels follow)
+// stem_fwd_v2_kernel is LDS-bound: every MFMA takes its own 16-byte pixel run (4-byte aligned: four ds_read_b32) from the ring,
+// 8 LDS cycles per 16-cycle MFMA and wave, four waves' worth per CU -- 2.5 x the matrix pipe's time (560 us for the metric
+// geometry against ~110 us of MFMAs).  The v3 design is INPUT-FRAME stationary: an input frame (2m + par) feeds every output pair
+// it reaches at once -- pairs m - 1, m, m + 1 (kt = 5) -- so one pixel run is read ONCE for up to three MFMAs (18 instead of 6
+// per 16 bytes), the three pairs' accumulators roll through registers (pair m - 1 is complete after input pair m and is
+// stored), and the filter lives in REGISTERS: the 36 A fragments (f', chunk) of the v2 matrix, where an input frame of
+// parity par meets pair m - 1 + r at window position f' = par + 2 - 2 r + PT.  LDS holds only the current and the next
+// input pair (4 frame patches); the ring of kt + 1 frames and its rotation are gone.
+// A unit is (clip, output tile, chunk of output pairs p0 .. p1 - 1) and walks input pairs p0 - 1 .. p1 (the two boundary
+// pairs feed one output pair each; pairs outside the unit are multiplied too and roll out unstored -- a branch per pair made
+// hipcc shuffle all 24 accumulator registers around every MFMA pair: 1,137 us); frames outside the clip are skipped.
+// Staging: 16-byte chunks, each load instruction within ONE frame so that the (clip, frame) base rides the instruction's scalar
+// offset (not range-checked) and the per-thread part is a 32-bit voffset computed once per unit (a 64-bit address per chunk
+// cost ~100 vector instructions per pair and wave); padding = voffset 2^31, a frame outside the clip reads through a
+// zero-sized resource; the physical frames of a unit are resolved ONCE into an LDS table (a frame-index load in the loop
+// would drain the loads in flight); a pair is fetched two iterations ahead.
+// First build (512 threads, 16 x 16 tiles): 560 -> 365 us alone; its phases ran one after the other (MFMAs 122 us, fetch /
+// stage 92, epilogue 56, pixel-run reads 48 by removal) -- the half-tile kernels below overlap them across workgroups.
+
 // 16-lane row sum with DPP shifts (4 vector instructions; __shfl_xor goes through ds_bpermute): the total ends in lane 15
 __device__ __forceinline__ float stem_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
@@ -595,244 +611,10 @@ __device__ __forceinline__ float stem_row16_sum(float v) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------ forward, v3
-// stem_fwd_v2_kernel is LDS-bound: every MFMA takes its own 16-byte pixel run (4-byte aligned: four ds_read_b32) from the ring,
-// 8 LDS cycles per 16-cycle MFMA and wave, four waves' worth per CU -- 2.5 x the matrix pipe's time (540 us for the metric
-// geometry against ~110 us of MFMAs).  v3 is INPUT-FRAME stationary: an input frame (2m + par) feeds every output pair it
-// reaches at once -- pairs m - 1, m, m + 1 (kt = 5) -- so one pixel run is read ONCE for up to three MFMAs (18 instead of 6
-// per 16 bytes), the three pairs' accumulators roll through registers (pair m - 1 is complete after input pair m and is
-// stored), and the filter lives in REGISTERS: the 36 A fragments (f', chunk) of the v2 matrix, where an input frame of
-// parity par meets pair m - 1 + r at window position f' = par + 2 - 2 r + PT.  LDS holds only the current and the next
-// input pair (4 frame patches); the ring of kt + 1 frames and its rotation are gone.
-// A unit is (clip, 16 x 16 output tile, chunk of output pairs p0 .. p1 - 1) and walks input pairs p0 - 1 .. p1 (the two
-// boundary pairs feed one output pair each); frames outside the clip are skipped.
-template <int CIN, int KT>
-__global__ __launch_bounds__(512, 2) void stem_fwd_v3_kernel(const StemK k, int pairs_per_unit, int nunits) {
-  constexpr int NF = KT + 1, PT = KT / 2;
-  constexpr int SLOT = CIN * F2_PLANE;
-  constexpr int CPF = CIN * 2;
-  constexpr int NCH = NF * CPF;
-  constexpr int FRAME_CHUNKS = CIN * F2_PR * 6;
-  constexpr int NXC = (2 * FRAME_CHUNKS + 511) / 512;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
-  char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
-  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [2][8 waves][16 rows][2]
-  int* fidx = reinterpret_cast<int*>(red + 2 * 8 * 16 * 2);       // [32] physical frame of the unit's logical frames (-1: zeros)
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bf16_t* yp = static_cast<bf16_t*>(k.y);
-  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
-  const int perm_g = ((g & 1) << 1) | (g >> 1);                  // {0,2,1,3}
-
-  // ---- A matrix as in v2: amat[chunk f'*CPF + c6][row (jt,co)][k = 8g + k'] = w[co][f'-jt][ci = c6>>1][kh][k'-1]
-  {
-    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
-    for (int e = tid; e < NCH * 64; e += 512) {
-      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
-      const int fp = ch / CPF, c6 = ch % CPF;
-      const int jt = row >> 3, co = row & 7, f = fp - jt;
-      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
-      bf16x8 v;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
-      if (f >= 0 && f < KT && co < k.cout && kh < KH) {
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + ((f * CIN + ci) * KH + kh) * 8);
-#pragma unroll
-        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
-      }
-      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
-    }
-  }
-  __syncthreads();
-  bf16x8 afr[NCH];
-  {
-    const int a_lane = a_off(l15, g);
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
-      asm volatile("" : "+v"(afr[ch]));             // loop-invariant registers, not re-loadable values
-    }
-  }
-
-  // ---- staging: three 16-byte chunks per thread and input pair, each load instruction within ONE frame so that the frame's
-  // base offset rides the instruction's scalar offset and the per-thread part (channel, patch row, chunk) is a 32-bit voffset
-  // computed once per unit (the first version rebuilt a 64-bit address per chunk and pair: ~100 vector instructions per pair
-  // and wave, a quarter of the kernel's time).  Slot 0 / 1: chunk tid of frame 0 / 1; slot 2: chunk 512 + (tid & 255) of frame
-  // tid >> 8 (waves 0-3 / 4-7).  Padding: a voffset past the resource reads zeros (the scalar offset is not range-checked);
-  // a frame outside the clip reads through a zero-sized resource.
-  static_assert(FRAME_CHUNKS > 512 && FRAME_CHUNKS <= 768, "three single-frame loads per thread cover a pair");
-  int x_row[3], x_col[3], x_chan[3], x_loc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int e = i < 2 ? tid : 512 + (tid & 255);
-    const int fr = i < 2 ? i : tid >> 8;
-    const int ci = e / (F2_PR * 6), rr = e % (F2_PR * 6);
-    x_row[i] = e < FRAME_CHUNKS ? rr / 6 : -1000000;               // (an unused slot is always out of range)
-    x_col[i] = 8 * (rr % 6);
-    x_chan[i] = (int)(ci * k.sc * 2);
-    x_loc[i] = fr * SLOT + ci * F2_PLANE + (rr / 6) * F2_PITCH + (rr % 6) * 16;
-  }
-  uint32_t xv[3];                                                // voffsets of the current unit
-  uint4 xra[3], xrb[3];                                          // two pairs in flight: a pair is fetched TWO iterations ahead
-  int n = 0, ho0 = 0, wo0 = 0, fbase = 0;                         // fbase: logical frame of fidx[0]
-  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
-  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
-  auto unit_offsets = [&]() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int hi = 2 * ho0 - 3 + x_row[i], wi = 2 * wo0 - 8 + x_col[i];
-      const bool ok = (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
-      xv[i] = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
-    }
-  };
-  auto fetch = [&](uint4 (&xr)[3], int F0) __attribute__((always_inline)) {        // frames F0, F0 + 1 (logical)
-    uint32_t so[2];
-    bool fok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = __builtin_amdgcn_readfirstlane(fidx[F0 + u - fbase]);      // (resolved once per unit: a frame-index load
-      fok[u] = f >= 0;                                                          // here would drain the loads in flight)
-      so[u] = fok[u] ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f * k.st) * 2) : 0u;
-    }
-    const int u2 = wave >> 2;                                    // slot 2's frame (wave-uniform)
-    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(fok[0] ? srs : srs0, (int)xv[0], (int)so[0], 0);
-    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(fok[1] ? srs : srs0, (int)xv[1], (int)so[1], 0);
-    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128((u2 ? fok[1] : fok[0]) ? srs : srs0, (int)xv[2], (int)(u2 ? so[1] : so[0]), 0);
-    xr[0] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
-    xr[1] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
-    xr[2] = make_uint4(v2[0], v2[1], v2[2], v2[3]);
-  };
-  auto stage = [&](const uint4 (&xr)[3], int buf) __attribute__((always_inline)) {
-    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[0]) = xr[0];
-    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[1]) = xr[1];
-    if (x_row[2] >= 0) *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[2]) = xr[2];
-  };
-
-  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
-  const int tpairs = (k.t_log + 1) / 2;
-  const int tchunks = (tpairs + pairs_per_unit - 1) / pairs_per_unit;
-
-  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-    const int tc = unit % tchunks;
-    int tile = unit / tchunks, th, tw;
-    tw = tile % k.tiles_w; tile /= k.tiles_w;
-    th = tile % k.tiles_h;
-    n = tile / k.tiles_h;
-    ho0 = th * TS; wo0 = tw * TS;
-    const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);
-    unit_offsets();
-    fbase = 2 * (p0 - 1);
-    if (tid < 2 * (p1 - p0 + 2)) {                     // the unit's logical frames 2 (p0 - 1) .. 2 p1 + 1 -> physical frames
-      const int F = fbase + tid;
-      int f = (F >= 0 && F < k.t_log) ? F : -1;
-      if (f >= 0 && k.t_index) f = k.t_index[f];
-      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
-    }
-    __syncthreads();                                   // the previous unit's patch reads are done; fidx is visible
-    fetch(xra, 2 * (p0 - 1));
-    stage(xra, 0);
-    fetch(xrb, 2 * p0);
-    __syncthreads();
-    f32x4 acc[3][2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // one input pair: fetch pair m + 2 into xf, multiply pair m out of buffer cur, store output pair m - 1, stage pair m + 1 (in
-    // xs since the previous iteration) into the other buffer
-    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[3], const uint4 (&xs)[3]) __attribute__((always_inline)) {
-      if (m + 2 <= p1 && SFK_STEM_EXP != 3) fetch(xf, 2 * (m + 2));
-      const bool on[3] = {m - 1 >= p0, m >= p0 && m < p1, m + 1 < p1};      // is output pair m - 1 + r inside this unit?
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int F = 2 * m + par;
-        if (F < 0 || F >= k.t_log) continue;           // temporal padding (wave-uniform)
-        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
-#pragma unroll
-        for (int c6 = 0; c6 < CPF; ++c6) {
-          bf16x8 bv[2];
-#if SFK_STEM_EXP == 4
-          bv[0] = afr[c6]; bv[1] = afr[c6 + 6];
-#else
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * F2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
-            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
-            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
-          }
-#endif
-#if SFK_STEM_EXP == 1
-          asm volatile("" ::"v"(bv[0]), "v"(bv[1]));
-#else
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            // window position of this frame for pair m - 1 + r (a literal after unrolling).  Pairs outside the unit are
-            // multiplied too: their accumulators roll out unstored, and a branch per pair made hipcc shuffle all 24
-            // accumulator registers around every MFMA pair (1,137 us against v2's 562)
-            const int fp = par + 2 - 2 * r + PT;
-            if (fp >= 0 && fp < NF) {
-              acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[0], acc[r][0], 0, 0, 0);
-              acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[fp * CPF + c6], bv[1], acc[r][1], 0, 0, 0);
-            }
-          }
-#endif
-        }
-      }
-      // ---- output pair m - 1 is complete: lane holds rows 4g..4g+3 = (jt = g>>1, co = 4*(g&1) + r) of pixel (2*wave + j, l15)
-      const int to0 = 2 * (m - 1);
-      float* redp = red + (m & 1) * (8 * 16 * 2);
-      if (on[0] && (SFK_STEM_EXP != 2 || m == p1)) {
-        const int jt = g >> 1, co0 = 4 * (g & 1), to = to0 + jt;
-        const int wo = wo0 + l15;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ho = ho0 + 2 * wave + j;
-          if (to < k.t_out && ho < k.ho && wo < k.wo && co0 < k.cout) {
-            store4(yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff + co0, acc[0][j]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[r] += acc[0][j][r]; s2[r] += acc[0][j][r] * acc[0][j][r]; }
-          }
-        }
-        if (k.stats) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = stem_row16_sum(s1[r]), c = stem_row16_sum(s2[r]);      // DPP row shifts: the total ends in lane 15 of the row
-            if (l15 == 15) {
-              redp[(wave * 16 + 4 * g + r) * 2 + 0] = a;
-              redp[(wave * 16 + 4 * g + r) * 2 + 1] = c;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      if (m < p1 && SFK_STEM_EXP != 3) stage(xs, cur ^ 1);
-      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged, red is complete
-      if (on[0] && k.stats && tid < 16) {
-        const int sjt = tid >> 3, sco = tid & 7, sto = to0 + sjt;
-        if (sto < k.t_out && sco < k.cout) {
-          float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-          for (int w_ = 0; w_ < 8; ++w_) { a1 += redp[(w_ * 16 + tid) * 2]; a2 += redp[(w_ * 16 + tid) * 2 + 1]; }
-          const int64_t trow = (((int64_t)n * k.t_out + sto) * k.tiles_h + th) * k.tiles_w + tw;
-          k.stats[(trow * k.cout + sco) * 2 + 0] = a1;
-          k.stats[(trow * k.cout + sco) * 2 + 1] = a2;
-        }
-      }
-    };
-    for (int m = p0 - 1;;) {
-      pair_iter(m, 0, xra, xrb);
-      if (++m > p1) break;
-      pair_iter(m, 1, xrb, xra);
-      if (++m > p1) break;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ forward, slow stem (kt = 1, 64 channels)
 // The canonical slow stem through stem_fwd_kernel stages its patch element by element (18 two-byte loads in flight per thread),
 // re-reads the filter from LDS every K-step, reduces its statistics with 128 ds_bpermute shuffles per tile and stores 8 bytes
-// per lane: 300 us alone for 32 us of MFMAs and 61 us of HBM traffic.  This kernel is stem_fwd_v3_kernel's machinery with the
+// per lane: 300 us alone for 32 us of MFMAs and 61 us of HBM traffic.  The slow-stem kernel below (stem_fwd_s4_kernel) is the v3 machinery with the
 // rows of the A fragments = 16 output channels (4 fragments, no temporal window): two frames per 16-byte-chunk fetch, two
 // fetches ahead, the 24 filter fragments in registers, one pixel run per FOUR MFMAs, DPP row sums, v_permlane16_swap between
 // channel fragments so that a lane stores 16 bytes (8 consecutive channels of a pixel).
@@ -842,227 +624,8 @@ __device__ __forceinline__ void stem_swap16(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
-template <int CIN>
-__global__ __launch_bounds__(512, 2) void stem_fwd_s3_kernel(const StemK k, int pairs_per_unit, int nunits) {
-  constexpr int SLOT = CIN * F2_PLANE;
-  constexpr int CPF = CIN * 2, NCF = 4, NCH = NCF * CPF;
-  constexpr int FRAME_CHUNKS = CIN * F2_PR * 6;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* pb = smem;                                               // [2 pair buffers][2 frames][CIN][38][96 B]
-  char* amat = smem + 4 * SLOT;                                  // [NCH][16 rows][64 B]: built once, read into registers
-  float* red = reinterpret_cast<float*>(amat + NCH * 1024);      // [8 waves][64 co][2]
-  int* fidx = reinterpret_cast<int*>(red + 8 * 64 * 2);          // [32]
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bf16_t* yp = static_cast<bf16_t*>(k.y);
-  auto a_off = [](int r, int sg) { return r * 64 + ((sg ^ ((4 - ((r >> 2) & 3)) & 3)) << 4); };
-  const int perm_g = ((g & 1) << 1) | (g >> 1);                  // {0,2,1,3}
-
-  // ---- A matrix: amat[chunk cf*CPF + c6][row][k = 8g + k'] = w[co = 16 cf + row][ci = c6>>1][kh][k'-1]
-  {
-    const bf16_t* wp = static_cast<const bf16_t*>(k.w);
-    for (int e = tid; e < NCH * 64; e += 512) {
-      const int ch = e >> 6, row = (e >> 2) & 15, gg = e & 3;
-      const int cf = ch / CPF, c6 = ch % CPF;
-      const int co = 16 * cf + row;
-      const int kh = (c6 & 1) * 4 + (((gg & 1) << 1) | (gg >> 1)), ci = c6 >> 1;
-      bf16x8 v;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)0.f;
-      if (co < k.cout && kh < KH) {
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (int64_t)co * k.kp + (ci * KH + kh) * 8);
-#pragma unroll
-        for (int i = 1; i < 8; ++i) v[i] = wv[i - 1];
-      }
-      *reinterpret_cast<bf16x8*>(amat + ch * 1024 + a_off(row, gg)) = v;
-    }
-  }
-  __syncthreads();
-  bf16x8 afr[NCH];
-  {
-    const int a_lane = a_off(l15, g);
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      afr[ch] = *reinterpret_cast<const bf16x8*>(amat + ch * 1024 + a_lane);
-      asm volatile("" : "+v"(afr[ch]));
-    }
-  }
-
-  // ---- staging: as stem_fwd_v3_kernel
-  static_assert(FRAME_CHUNKS > 512 && FRAME_CHUNKS <= 768, "three single-frame loads per thread cover a pair");
-  int x_row[3], x_col[3], x_chan[3], x_loc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int e = i < 2 ? tid : 512 + (tid & 255);
-    const int fr = i < 2 ? i : tid >> 8;
-    const int ci = e / (F2_PR * 6), rr = e % (F2_PR * 6);
-    x_row[i] = e < FRAME_CHUNKS ? rr / 6 : -1000000;
-    x_col[i] = 8 * (rr % 6);
-    x_chan[i] = (int)(ci * k.sc * 2);
-    x_loc[i] = fr * SLOT + ci * F2_PLANE + (rr / 6) * F2_PITCH + (rr % 6) * 16;
-  }
-  uint32_t xv[3];
-  uint4 xra[3], xrb[3];
-  int n = 0, ho0 = 0, wo0 = 0, fbase = 0;
-  const __amdgpu_buffer_rsrc_t srs = sfk_make_rsrc(k.src, k.src_bytes);
-  const __amdgpu_buffer_rsrc_t srs0 = sfk_make_rsrc(k.src, 0);
-  auto unit_offsets = [&]() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int hi = 2 * ho0 - 3 + x_row[i], wi = 2 * wo0 - 8 + x_col[i];
-      const bool ok = (unsigned)hi < (unsigned)k.h_in && wi >= 0 && wi + 8 <= k.w_in;
-      xv[i] = ok ? (uint32_t)(x_chan[i] + (hi * (int)k.sh + wi) * 2) : 0x80000000u;
-    }
-  };
-  auto fetch = [&](uint4 (&xr)[3], int F0) __attribute__((always_inline)) {
-    uint32_t so[2];
-    bool fok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = __builtin_amdgcn_readfirstlane(fidx[F0 + u - fbase]);
-      fok[u] = f >= 0;
-      so[u] = fok[u] ? (uint32_t)(((int64_t)n * k.sn + (int64_t)f * k.st) * 2) : 0u;
-    }
-    const int u2 = wave >> 2;
-    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(fok[0] ? srs : srs0, (int)xv[0], (int)so[0], 0);
-    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(fok[1] ? srs : srs0, (int)xv[1], (int)so[1], 0);
-    const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128((u2 ? fok[1] : fok[0]) ? srs : srs0, (int)xv[2], (int)(u2 ? so[1] : so[0]), 0);
-    xr[0] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
-    xr[1] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
-    xr[2] = make_uint4(v2[0], v2[1], v2[2], v2[3]);
-  };
-  auto stage = [&](const uint4 (&xr)[3], int buf) __attribute__((always_inline)) {
-    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[0]) = xr[0];
-    *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[1]) = xr[1];
-    if (x_row[2] >= 0) *reinterpret_cast<uint4*>(pb + buf * 2 * SLOT + x_loc[2]) = xr[2];
-  };
-
-  const int b_lane = (4 * wave + perm_g) * F2_PITCH + (2 * l15 + 4) * 2;
-  const int tpairs = (k.t_log + 1) / 2;
-  const int tchunks = (tpairs + pairs_per_unit - 1) / pairs_per_unit;
-
-  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-    const int tc = unit % tchunks;
-    int tile = unit / tchunks, th, tw;
-    tw = tile % k.tiles_w; tile /= k.tiles_w;
-    th = tile % k.tiles_h;
-    n = tile / k.tiles_h;
-    ho0 = th * TS; wo0 = tw * TS;
-    const int p0 = tc * pairs_per_unit, p1 = min(p0 + pairs_per_unit, tpairs);      // input = output pairs p0 .. p1 - 1
-    unit_offsets();
-    fbase = 2 * p0;
-    if (tid < 2 * (p1 - p0 + 1)) {
-      const int F = fbase + tid;
-      int f = (F >= 0 && F < k.t_log) ? F : -1;
-      if (f >= 0 && k.t_index) f = k.t_index[f];
-      fidx[tid] = (f >= 0 && f < k.t_in) ? f : -1;
-    }
-    __syncthreads();                                   // the previous unit's patch reads are done; fidx is visible
-    fetch(xra, 2 * p0);
-    stage(xra, 0);
-    if (p0 + 1 < p1) fetch(xrb, 2 * (p0 + 1));
-    __syncthreads();
-    // BatchNorm partial sums of the WHOLE unit (all its frames) in one statistics row -- the row of its first frame's tile; the
-    // rows of the other frames get zeros (the consumer folds all rows).  Per frame that is 64 multiply-adds instead of 64 + 128
-    // DPP adds: the epilogue's vector instructions, not the MFMAs, bound the first version (280 against 48 x 16 cycles).
-    float s1[NCF][4], s2[NCF][4];
-#pragma unroll
-    for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s1[cf][r] = s2[cf][r] = 0.f;
-    auto pair_iter = [&](const int m, const int cur, uint4 (&xf)[3], const uint4 (&xs)[3]) __attribute__((always_inline)) {
-      if (m + 2 < p1) fetch(xf, 2 * (m + 2));
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int to = 2 * m + par;
-        if (to >= k.t_out) continue;                   // odd clip length (wave-uniform)
-        const char* bb = pb + (cur * 2 + par) * SLOT + b_lane;
-        f32x4 acc[NCF][2];
-#pragma unroll
-        for (int cf = 0; cf < NCF; ++cf) acc[cf][0] = acc[cf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c6 = 0; c6 < CPF; ++c6) {
-          bf16x8 bv[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(bb + (c6 >> 1) * F2_PLANE + (2 * j + 4 * (c6 & 1)) * F2_PITCH);
-            uint4 t4 = make_uint4(q[0], q[1], q[2], q[3]);
-            bv[j] = *reinterpret_cast<const bf16x8*>(&t4);
-          }
-#pragma unroll
-          for (int cf = 0; cf < NCF; ++cf) {
-            acc[cf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[0], acc[cf][0], 0, 0, 0);
-            acc[cf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cf * CPF + c6], bv[1], acc[cf][1], 0, 0, 0);
-          }
-        }
-        // ---- epilogue of output frame `to`: lane holds channels 16 cf + 4 g + r of pixel (2 wave + j, l15)
-        const int wo = wo0 + l15;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ho = ho0 + 2 * wave + j;
-          const bool pok = ho < k.ho && wo < k.wo;
-          if (pok) {
-#pragma unroll
-            for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { s1[cf][r] += acc[cf][j][r]; s2[cf][r] += acc[cf][j][r] * acc[cf][j][r]; }
-          }
-          bf16_t* pix = yp + ((((int64_t)n * k.t_out + to) * k.ho + ho) * k.wo + wo) * k.yld + k.yoff;
-#pragma unroll
-          for (int cp = 0; cp < NCF; cp += 2) {        // fragments cp, cp + 1 -> 8 consecutive channels per lane
-            float v[8] = {acc[cp][j][0], acc[cp][j][1], acc[cp][j][2], acc[cp][j][3],
-                          acc[cp + 1][j][0], acc[cp + 1][j][1], acc[cp + 1][j][2], acc[cp + 1][j][3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) stem_swap16(v[e], v[4 + e]);
-            const int co = 16 * cp + 16 * (g & 1) + 8 * (g >> 1);
-            if (pok && co < k.cout) {
-              bf16x8 o;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-              *reinterpret_cast<bf16x8*>(pix + co) = o;
-            }
-          }
-        }
-      }
-      if (m + 1 < p1) stage(xs, cur ^ 1);
-      __syncthreads();                                 // this pair's patch reads are done, the next pair is staged
-    };
-    for (int m = p0;;) {
-      pair_iter(m, 0, xra, xrb);
-      if (++m >= p1) break;
-      pair_iter(m, 1, xrb, xra);
-      if (++m >= p1) break;
-    }
-    if (k.stats) {
-#pragma unroll
-      for (int cf = 0; cf < NCF; ++cf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = stem_row16_sum(s1[cf][r]), c = stem_row16_sum(s2[cf][r]);
-          if (l15 == 15) {
-            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 0] = a;
-            red[(wave * 64 + 16 * cf + 4 * g + r) * 2 + 1] = c;
-          }
-        }
-      __syncthreads();
-      const int nfr = min(2 * p1, k.t_out) - 2 * p0;       // output frames of this unit
-      for (int e = tid; e < nfr * k.cout; e += 512) {
-        const int fr = e / k.cout, co = e - fr * k.cout;
-        float a1 = 0.f, a2 = 0.f;
-        if (fr == 0) {
-#pragma unroll
-          for (int w_ = 0; w_ < 8; ++w_) { a1 += red[(w_ * 64 + co) * 2]; a2 += red[(w_ * 64 + co) * 2 + 1]; }
-        }
-        const int64_t trow = (((int64_t)n * k.t_out + 2 * p0 + fr) * k.tiles_h + th) * k.tiles_w + tw;
-        k.stats[(trow * k.cout + co) * 2 + 0] = a1;
-        k.stats[(trow * k.cout + co) * 2 + 1] = a2;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ forward, half tiles (256 threads)
-// stem_fwd_v3_kernel / stem_fwd_s3_kernel are 512-thread workgroups with ~235 registers per lane: ONE workgroup owns a CU's whole
+// The first builds of the v3 design were 512-thread workgroups with ~235 registers per lane: ONE workgroup owns a CU's whole
 // register file, so (a) its phases -- fetch, MFMAs, epilogue, barrier -- run strictly one after the other (measured: the parts
 // add up), and (b) while one stem's persistent workgroups hold the CUs nothing else becomes resident: the two stems ran one after
 // the other and the slow pathway's small kernels waited (bn_finalize 139 us in the step's timeline).  The kernels below are the
@@ -1134,7 +697,7 @@ struct H2Unit {
   }
 };
 
-// fast stem: stem_fwd_v3_kernel on half tiles
+// fast stem
 template <int CIN, int KT>
 __global__ __launch_bounds__(256, 2) void stem_fwd_v4_kernel(const StemK k, int pairs_per_unit, int nunits, int tchunks) {
   constexpr int NF = KT + 1, PT = KT / 2;
@@ -1292,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_v4_kernel(const StemK k, int 
   }
 }
 
-// slow stem: stem_fwd_s3_kernel on half tiles
+// slow stem (kt = 1, 64 output channels = 4 A fragments per chunk, no temporal window)
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void stem_fwd_s4_kernel(const StemK k, int pairs_per_unit, int nunits, int tchunks) {
   constexpr int SLOT = CIN * H2_PLANE;
@@ -1681,13 +1244,12 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
     hipStream_t hs2 = static_cast<hipStream_t>(stream);
     const int nf = s->kt + 1;
     const int lds2 = nf * 3 * F2_PLANE + nf * 6 * 1024 + 8 * 16 * 2 * 4;
-    const int lds3 = 4 * 3 * F2_PLANE + nf * 6 * 1024 + 2 * 8 * 16 * 2 * 4 + 32 * 4;
-    const bool v3 = (sfk_tune().stem_v3 & 1) != 0 && stem_src_extent(s, y->n) < (1ll << 31);      // (v3 marks padding with voffset 2^31)
     const int tpairs = (k.t_log + 1) / 2;
     const int ppu = tpairs < 8 ? tpairs : 8;
     const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
     const int grid2 = nunits < 256 ? nunits : 256;
-    if (v3 && (sfk_tune().stem_v3 & 4) && k.t_log >= 2) {        // half tiles: two workgroups per CU
+    const bool v3 = (sfk_tune().stem_v3 & 1) != 0 && stem_src_extent(s, y->n) < (1ll << 31) && k.t_log >= 2;      // (padding = voffset 2^31)
+    if (v3) {                                                      // half tiles, two workgroups per CU
       const int nfull = k.t_log / 2, tch = nfull <= ppu ? 1 : (nfull + ppu - 1) / ppu;
       const int nu = y->n * ((y->h + H2_ROWS - 1) / H2_ROWS) * k.tiles_w * tch;
       const int grid4 = nu < 512 ? nu : 512;
@@ -1699,12 +1261,6 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v4_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         hipLaunchKernelGGL((stem_fwd_v4_kernel<3, 3>), dim3((unsigned)grid4), dim3(256), lds4, hs2, k, ppu, nu, tch);
       }
-    } else if (v3 && s->kt == 5) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v3_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-      hipLaunchKernelGGL((stem_fwd_v3_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds3, hs2, k, ppu, nunits);
-    } else if (v3) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v3_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-      hipLaunchKernelGGL((stem_fwd_v3_kernel<3, 3>), dim3((unsigned)grid2), dim3(512), lds3, hs2, k, ppu, nunits);
     } else if (s->kt == 5) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_v2_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
       hipLaunchKernelGGL((stem_fwd_v2_kernel<3, 5>), dim3((unsigned)grid2), dim3(512), lds2, hs2, k, ppu, nunits);
@@ -1718,27 +1274,17 @@ extern "C" int sfk_stem_conv_fwd(const sfk_stem_src* s, const void* w, const sfk
   // canonical slow stem geometry in bf16: the register-filter kernel above
   if ((sfk_tune().stem_v3 & 2) && y->dtype == SFK_BF16 && s->src_dtype == SFK_BF16 && s->cin == 3 && s->kt == 1 && y->c == 64 &&
       s->sw == 1 && (s->w_in % 8) == 0 && !((s->sn | s->sc | s->st | s->sh) & 7) && !(((uintptr_t)s->src) & 15) &&
-      !(y->ld % 8) && !(y->c_off % 8) && stem_src_extent(s, y->n) < (1ll << 31)) {
+      !(y->ld % 8) && !(y->c_off % 8) && stem_src_extent(s, y->n) < (1ll << 31) && k.t_log >= 2) {
     k.src_bytes = (uint32_t)stem_src_extent(s, y->n);
     k.y_bytes = 0;
     hipStream_t hs3 = static_cast<hipStream_t>(stream);
-    const int lds = 4 * 3 * F2_PLANE + 24 * 1024 + 8 * 64 * 2 * 4 + 32 * 4;
-    const int tpairs = (k.t_log + 1) / 2;
-    const int ppu = tpairs < 2 ? tpairs : 2;
-    const int nunits = y->n * k.tiles_h * k.tiles_w * ((tpairs + ppu - 1) / ppu);
-    const int grid = nunits < 256 ? nunits : 256;
-    if ((sfk_tune().stem_v3 & 8) && k.t_log >= 2) {              // half tiles: two workgroups per CU
-      const int nfull = k.t_log / 2, tch = nfull <= ppu ? 1 : (nfull + ppu - 1) / ppu;
-      const int nu = y->n * ((y->h + H2_ROWS - 1) / H2_ROWS) * k.tiles_w * tch;
-      const int grid4 = nu < 512 ? nu : 512;
-      const int lds4 = 4 * 3 * H2_PLANE + 24 * 1024 + 4 * 64 * 2 * 4 + 32 * 4;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-      hipLaunchKernelGGL((stem_fwd_s4_kernel<3>), dim3((unsigned)grid4), dim3(256), lds4, hs3, k, ppu, nu, tch);
-      SFK_CHECK_LAUNCH();
-      return SFK_OK;
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((stem_fwd_s3_kernel<3>), dim3((unsigned)grid), dim3(512), lds, hs3, k, ppu, nunits);
+    const int ppu = 2;
+    const int nfull = k.t_log / 2, tch = nfull <= ppu ? 1 : (nfull + ppu - 1) / ppu;
+    const int nu = y->n * ((y->h + H2_ROWS - 1) / H2_ROWS) * k.tiles_w * tch;
+    const int grid4 = nu < 512 ? nu : 512;
+    const int lds4 = 4 * 3 * H2_PLANE + 24 * 1024 + 4 * 64 * 2 * 4 + 32 * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_s4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+    hipLaunchKernelGGL((stem_fwd_s4_kernel<3>), dim3((unsigned)grid4), dim3(256), lds4, hs3, k, ppu, nu, tch);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
   }
