@@ -15,4 +15,7 @@ done
 # the deep-pipelined tiles with every case eligible: 224-row conv tiles (SFK_P8=3), filter-gradient tile from 2 K-tiles per workgroup (SFK_WGP8=2)
 SFK_P8=3 SFK_WGP8=2 timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -p no:cacheprovider -k "p8 or conv_forward or data_gradient or filter_gradient" > gpurun_out/test_gpu_kernels_p8.log 2>&1
 echo "test_gpu_kernels (SFK_P8=3 SFK_WGP8=2) exit $?: $(tail -n 1 gpurun_out/test_gpu_kernels_p8.log)" | tee -a gpurun_out/tests_summary.log
+# the kernels the new paths replace stay callable: band filter gradient off, v2 stem forward / generic slow stem, band conv off
+SFK_WGBAND=0 SFK_STEM3=0 SFK_HALO=0 timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 600 -p no:cacheprovider -k "stem or filter_gradient or conv_forward or data_gradient" > gpurun_out/test_gpu_kernels_old.log 2>&1
+echo "test_gpu_kernels (SFK_WGBAND=0 SFK_STEM3=0 SFK_HALO=0) exit $?: $(tail -n 1 gpurun_out/test_gpu_kernels_old.log)" | tee -a gpurun_out/tests_summary.log
 exit 0
