@@ -15,7 +15,7 @@ CLASSES = [  # substring of the kernel name -> bench.py stage name (first match 
     ("bn_pool_bwd_kernelIDF16bLb0", "bn_bwd_reduce"), ("bn_pool_bwd_kernelIfLb0", "bn_bwd_reduce"), ("bn_pool_bwd_kernel", "bn_bwd_apply"),
     ("E, true>((anonymous namespace)::FM, ELi, unsigned char*", "bn_apply"),      # maxpool_fwd_kernel<..., BN = true>
     ("conv_igemm", "conv_igemm"), ("conv_halo", "conv_igemm"), ("conv_pw_fused", "conv_igemm"), ("pw_dual", "conv_igemm"),
-    ("conv_wgrad", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"),
+    ("conv_wgrad", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"), ("band_reduce", "conv_wgrad"),
     ("bn_tail", "bn_finalize"), ("stem_fwd", "stem_fwd"), ("stem_wgrad", "stem_wgrad"),
     ("bn_bwd_reduce", "bn_bwd_reduce"), ("bn_bwd_apply", "bn_bwd_apply"), ("bn_apply", "bn_apply"),
     ("bn_fold", "bn_finalize"), ("bn_finalize", "bn_finalize"), ("bn_bwd_finalize", "bn_finalize"), ("relu_bits", "bn_bwd_reduce"),

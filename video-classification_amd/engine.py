@@ -488,7 +488,7 @@ class Engine:
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
             pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
                                               self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
-                                              self._fold_ws(tag, L.c)))
+                                              self._fold_ws(tag, L.c)), kind="bn_finalize")
             rec = _UnitRec(L, x, y, mean, invstd, scale, shift)
         else:
             self._conv(pl, L, x, y, None)
@@ -527,7 +527,7 @@ class Engine:
                           + (rec.y.pixels * L.c // self.kvec if bits is not None else 0))
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                               self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
-                                              self._fold_ws(tag, L.c)))
+                                              self._fold_ws(tag, L.c)), kind="bn_finalize")
         pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
         if dz_inplace:   # the mask is already applied to da
             pl.bwd.append(self.be.bn_bwd_apply(da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False,
@@ -684,7 +684,7 @@ class Engine:
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
             pl.fwd.append(self.be.bn_finalize(st["stats"], mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
                                               self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
-                                              self._fold_ws(tag, L.c)))
+                                              self._fold_ws(tag, L.c)), kind="bn_finalize")
             rec = _UnitRec(L, None, y, mean, invstd, scale, shift)
         else:
             self._stem_ops(pl, p, x5, t_index)
@@ -718,7 +718,7 @@ class Engine:
             pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key, bytes=rd)
             pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                                   self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
-                                                  self._fold_ws(tag, L.c)))
+                                                  self._fold_ws(tag, L.c)), kind="bn_finalize")
             pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
             pl.bwd.append(self.be.bn_maxpool_bwd_apply(d_out, argmax, y, rec.mean, rec.invstd, rec.scale, rec.shift, coef, da),
                           kind="bn_bwd_apply", layer=L.cb.norm_key, bytes=rd + float(esz * y.pixels * L.c))
