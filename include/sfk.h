@@ -39,8 +39,9 @@ extern "C" {
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 (retired in 15); 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
- * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band; 17 = sfk_tuning.stem_v3. */
-#define SFK_ABI_VERSION 17
+ * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band; 17 = sfk_tuning.stem_v3; 18 = sfk_bn_finalize_apply,
+ * sfk_bn_bwd_finalize_apply. */
+#define SFK_ABI_VERSION 18
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -270,6 +271,18 @@ int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
                  const float* res_scale, const float* res_shift, int32_t relu, const sfk_fmap* out,
                  uint8_t* relu_bits, float* out_sums, int32_t max_parts, int32_t* nparts_out, sfk_stream_t stream);
 
+/* sfk_bn_finalize + sfk_bn_apply in ONE launch: the apply's first workgroups fold the partial rows (the same deterministic block
+ * sums: results bit-identical to the two calls), every workgroup waits for their counter before it reads scale / shift.  The
+ * step's finalize launches are 8 us kernels on dependent chains behind a dispatch gap each; as a prologue the fold runs under
+ * the dispatch ramp of the consumer's own grid.  Arguments as the two calls (c = y->c; out_sums is not available here);
+ * sync: 2 int32 of the caller's, ZERO before the first call and left zero by every call (one pair per BatchNorm that may be in
+ * flight at the same time). */
+int sfk_bn_finalize_apply(const float* partials, int32_t nparts, int64_t count, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float* mean, float* invstd, float* workspace, int32_t* sync, const sfk_fmap* y, float* scale,
+                          float* shift, const sfk_fmap* res, const float* res_scale, const float* res_shift, int32_t relu,
+                          const sfk_fmap* out, uint8_t* relu_bits, sfk_stream_t stream);
+
 /* Backward of a = act(bn(y) [+ shortcut]) given dA:
  *   dz = dA * mask,   mask = relu_bits (as written by sfk_bn_apply) if given, else (mask_src > 0) if mask_src,
  *                     else (y*scale+shift > 0) if relu, else 1
@@ -288,6 +301,11 @@ int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_t c, int64_
 int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean,
                      const float* invstd, const float* scale, const float* shift, int32_t relu,
                      const float* coef, const sfk_fmap* dy, sfk_stream_t stream);
+/* sfk_bn_bwd_finalize + sfk_bn_bwd_apply in one launch (see sfk_bn_finalize_apply; results bit-identical to the two calls). */
+int sfk_bn_bwd_finalize_apply(const float* partials, int32_t nparts, int64_t count, const float* gamma, float* dgamma,
+                              float* dbeta, float* coef, float* workspace, int32_t* sync, const sfk_fmap* da, const sfk_fmap* y,
+                              const sfk_fmap* mask_src, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, int32_t relu, const sfk_fmap* dy, sfk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * The block tail  a -> conv_c (1x1x1, bias=False) -> norm_c (BatchNorm3d) [-> + shortcut -> ReLU]  WITHOUT the conv output

@@ -286,6 +286,27 @@ class EmuBackend:
                 nbt.add_(1)
         return run
 
+    def bn_finalize_apply(self, partials, nparts, count, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, workspace, sync, y,
+                          scale, shift, res, res_scale, res_shift, relu, out, relu_bits=None):
+        """the fused launch = the two stand-alone steps (sfk_bn_finalize_apply)"""
+        fin = self.bn_finalize(partials, nparts, y.c, count, gamma, beta, eps, momentum, rm, rv, nbt, mean, invstd, scale, shift, workspace)
+        app = self.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=relu_bits)
+
+        def run(stream):
+            fin(stream)
+            app(stream)
+        return run
+
+    def bn_bwd_finalize_apply(self, partials, nparts, count, gamma, dgamma, dbeta, coef, workspace, sync, da, y, mask_src, mean, invstd,
+                              scale, shift, relu, dy):
+        fin = self.bn_bwd_finalize(partials, nparts, y.c, count, gamma, invstd, dgamma, dbeta, coef, workspace)
+        app = self.bn_bwd_apply(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy)
+
+        def run(stream):
+            fin(stream)
+            app(stream)
+        return run
+
     def bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift):
         def run(stream):
             is_ = 1.0 / torch.sqrt(rv[:c] + eps)

@@ -570,6 +570,73 @@ def test_batchnorm_partial_fold_two_level(hip, c, nparts):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("c,dims", [(8, (2, 3, 40, 56)), (64, (2, 2, 28, 28)), (256, (1, 2, 14, 14)), (2048, (1, 1, 3, 3))],
+                         ids=lambda v: str(v) if isinstance(v, int) else "x".join(map(str, v)))
+def test_batchnorm_finalize_rides_the_apply_launch(hip, dtype, c, dims):
+    """sfk_bn_finalize_apply / sfk_bn_bwd_finalize_apply: the consumer's first workgroups fold the partial rows, the others wait
+    for their counter.  Everything the two stand-alone calls write must come out bit for bit -- coefficients, running statistics,
+    outputs, ReLU bitmap, dgamma / dbeta (accumulated into non-zero values) -- three launches in a row on the same counters (the last
+    workgroup resets them), with and without a shortcut, on grids smaller and larger than the number of channel pairs."""
+    n, t, h, w = dims
+    px = n * t * h * w
+    gen = torch.Generator().manual_seed(11 + c)
+    _, y = fmap_pair(n, c, t, h, w, dtype, gen, ld=c + 8, c_off=8)
+    _, res = fmap_pair(n, c, t, h, w, dtype, gen)
+    gamma, beta = (torch.rand(c, generator=gen) + 0.5).to(DEV), (torch.randn(c, generator=gen) * 0.3).to(DEV)
+    f = lambda *s_, **k: torch.zeros(*s_, device=DEV, **k)
+    st = stream()
+    parts = f(2048 * c * 2)
+    run, npart = hip.bn_stats(y, parts, 2048)
+    run(st)
+    vec = 8 if dtype == torch.bfloat16 else 4
+
+    def forward(fused, sync, with_res):
+        rm, rv, nbt = f(c) + 0.25, torch.ones(c, device=DEV), f(1, dtype=torch.int64)
+        mean, invstd, scale, shift = f(c), f(c), f(c), f(c)
+        out = FMap(torch.zeros(px * c, dtype=dtype, device=DEV), n, t, h, w, c)
+        bits = torch.zeros(px * c // vec, dtype=torch.uint8, device=DEV)
+        r = res if with_res else None
+        for _ in range(3):          # running statistics move three times; the counters come back to zero every time
+            if fused:
+                hip.bn_finalize_apply(parts, npart, px, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, invstd, None, sync, y, scale, shift,
+                                      r, None, None, True, out, relu_bits=bits)(st)
+            else:
+                hip.bn_finalize(parts, npart, c, px, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, invstd, scale, shift)(st)
+                hip.bn_apply(y, scale, shift, r, None, None, True, out, relu_bits=bits)(st)
+        return dict(rm=rm, rv=rv, nbt=nbt, mean=mean, invstd=invstd, scale=scale, shift=shift, out=out.buf, bits=bits)
+
+    def backward(fused, sync, fw, masked):
+        da = FMap(mk((px * c,), dtype, torch.Generator().manual_seed(5)).to(DEV), n, t, h, w, c)
+        bparts = f(2048 * c * 2)
+        run, nb = hip.bn_bwd_reduce(da, y, None, fw["mean"], fw["invstd"], fw["scale"], fw["shift"], True, da if masked else None, bparts, 2048)
+        run(st)
+        dgamma, dbeta, coef = f(c) + 1.5, f(c) - 0.5, f(c * 3)
+        dy = FMap(torch.zeros(px * c, dtype=dtype, device=DEV), n, t, h, w, c)
+        for _ in range(2):
+            if fused:
+                hip.bn_bwd_finalize_apply(bparts, nb, px, gamma, dgamma, dbeta, coef, None, sync, da, y, None, fw["mean"], fw["invstd"],
+                                          fw["scale"], fw["shift"], not masked, dy)(st)
+            else:
+                hip.bn_bwd_finalize(bparts, nb, c, px, gamma, fw["invstd"], dgamma, dbeta, coef)(st)
+                hip.bn_bwd_apply(da, y, None, fw["mean"], fw["invstd"], fw["scale"], fw["shift"], not masked, coef, dy)(st)
+        return dict(dgamma=dgamma, dbeta=dbeta, coef=coef, dy=dy.buf)
+
+    sync = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for with_res in (False, True):
+        a, b = forward(False, None, with_res), forward(True, sync, with_res)
+        torch.cuda.synchronize()
+        for k_ in a:
+            assert torch.equal(a[k_], b[k_]), ("forward", with_res, k_)
+        assert int(sync.abs().sum()) == 0
+    for masked in (False, True):
+        ba, bb = backward(False, None, a, masked), backward(True, sync, a, masked)
+        torch.cuda.synchronize()
+        for k_ in ba:
+            assert torch.equal(ba[k_], bb[k_]), ("backward", masked, k_)
+        assert int(sync.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("c", [8, 64, 80, 2048], ids=lambda c: f"c{c}")
 def test_batchnorm_forward_backward(hip, dtype, c):
     gen = torch.Generator().manual_seed(c)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 17       # include/sfk.h SFK_ABI_VERSION
+ABI_VERSION = 18       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -237,6 +237,10 @@ SIGNATURES = {
     "sfk_bn_eval_coeffs": [_PF, _PF, _PF, _PF, _F, _I32, _PF, _PF, _PV],
     "sfk_bn_stats": [_P_FMAP, _PF, _I32, C.POINTER(C.c_int32), _PV],
     "sfk_bn_apply": [_P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF, _I32, _P_FMAP, _PV, _PF, _I32, C.POINTER(C.c_int32), _PV],
+    "sfk_bn_finalize_apply": [_PF, _I32, _I64, _PF, _PF, _F, _F, _PF, _PF, _PV, _PF, _PF, _PF, _PV, _P_FMAP, _PF, _PF, _P_FMAP, _PF, _PF,
+                              _I32, _P_FMAP, _PV, _PV],
+    "sfk_bn_bwd_finalize_apply": [_PF, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PV, _P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32,
+                                  _P_FMAP, _PV],
     "sfk_bn_bwd_reduce": [_P_FMAP, _P_FMAP, _P_FMAP, _PF, _PF, _PF, _PF, _I32, _P_FMAP, _PF, _I32,
                           C.POINTER(C.c_int32), _PV, _PV],
     "sfk_bn_bwd_finalize": [_PF, _I32, _I32, _I64, _PF, _PF, _PF, _PF, _PF, _PF, _PV],
@@ -518,6 +522,31 @@ class HipBackend:
         return self._plain("sfk_bn_finalize", _ptr(partials), nparts, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
                            _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd), _ptr(scale),
                            _ptr(shift), _ptr(workspace), keep=ts)
+
+    def bn_finalize_apply(self, partials, nparts, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
+                          workspace, sync, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap,
+                          relu_bits=None):
+        """bn_finalize + bn_apply in one launch (sfk_bn_finalize_apply); sync: 2 zeroed int32 of this BatchNorm's own"""
+        fy, fo = _c_fmap(y), _c_fmap(out)
+        fr = _c_fmap(res) if res is not None else None
+        assert sync.dtype == torch.int32 and sync.numel() >= 2
+        ts = (partials, gamma, beta, running_mean, running_var, nbt, mean, invstd, workspace, sync, fy, fo, fr, y, out, res, scale, shift,
+              res_scale, res_shift, relu_bits)
+        return self._plain("sfk_bn_finalize_apply", _ptr(partials), nparts, count, _ptr(gamma), _ptr(beta), eps, momentum,
+                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(mean), _ptr(invstd), _ptr(workspace), _ptr(sync),
+                           C.byref(fy), _ptr(scale), _ptr(shift), C.byref(fr) if fr else None, _ptr(res_scale), _ptr(res_shift),
+                           1 if relu else 0, C.byref(fo), _ptr(relu_bits), keep=ts)
+
+    def bn_bwd_finalize_apply(self, partials, nparts, count, gamma, dgamma, dbeta, coef, workspace, sync, da: FMap, y: FMap,
+                              mask_src: Optional[FMap], mean, invstd, scale, shift, relu: bool, dy: FMap):
+        """bn_bwd_finalize + bn_bwd_apply in one launch (sfk_bn_bwd_finalize_apply)"""
+        fa, fy, fo = _c_fmap(da), _c_fmap(y), _c_fmap(dy)
+        fm = _c_fmap(mask_src) if mask_src is not None else None
+        assert sync.dtype == torch.int32 and sync.numel() >= 2
+        ts = (partials, gamma, dgamma, dbeta, coef, workspace, sync, fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift)
+        return self._plain("sfk_bn_bwd_finalize_apply", _ptr(partials), nparts, count, _ptr(gamma), _ptr(dgamma), _ptr(dbeta), _ptr(coef),
+                           _ptr(workspace), _ptr(sync), C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean), _ptr(invstd),
+                           _ptr(scale), _ptr(shift), 1 if relu else 0, C.byref(fo), keep=ts)
 
     def bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift):
         return self._plain("sfk_bn_eval_coeffs", _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), eps, c, _ptr(scale),

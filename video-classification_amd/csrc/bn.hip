@@ -230,29 +230,80 @@ __device__ __forceinline__ void block_sum_partials(const float* __restrict__ par
   s2 = red[(tid & 1) * 2 + 1][0];
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int nparts, int c, double count,
-                                                          const float* gamma, const float* beta, float eps,
-                                                          float momentum, float* running_mean, float* running_var,
-                                                          int64_t* nbt, float* mean, float* invstd, float* scale,
-                                                          float* shift) {
-  const int ch = blockIdx.x * 2 + (threadIdx.x & 1);         // c is a multiple of 2 (checked by the callers)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+// what one 256-thread block does for channel pair `pair` (channels 2 pair, 2 pair + 1)
+struct FinK {
+  const float* partials;       // nullptr: no fused finalize
+  int nparts, c;
+  double count;
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float* running_mean; float* running_var;
+  int64_t* nbt;
+  float* mean; float* invstd; float* scale; float* shift;
+  int* sync;                   // [2] zero before the first launch: finalize workgroups done, workgroups that left
+};
+
+__device__ __forceinline__ void bn_finalize_pair(const FinK& f, int pair) {
+  const int ch = pair * 2 + (threadIdx.x & 1);         // c is a multiple of 2 (checked by the callers)
   double s1, s2;
-  block_sum_partials(partials, nparts, c, blockIdx.x * 2, s1, s2);
+  block_sum_partials(f.partials, f.nparts, f.c, pair * 2, s1, s2);
   if (threadIdx.x > 1) return;
-  const double mu = s1 / count;
-  double var = s2 / count - mu * mu;
+  const double mu = s1 / f.count;
+  double var = s2 / f.count - mu * mu;
   if (var < 0.0) var = 0.0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[ch] * is;
-  mean[ch] = (float)mu;
-  invstd[ch] = is;
-  scale[ch] = sc;
-  shift[ch] = beta[ch] - (float)mu * sc;
-  if (running_mean) {
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mu;
-    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+  const float sc = f.gamma[ch] * is;
+  f.mean[ch] = (float)mu;
+  f.invstd[ch] = is;
+  f.scale[ch] = sc;
+  f.shift[ch] = f.beta[ch] - (float)mu * sc;
+  if (f.running_mean) {
+    const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+    f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * (float)mu;
+    f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const FinK f) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && f.nbt) f.nbt[0] += 1;
+  bn_finalize_pair(f, blockIdx.x);
+}
+
+// ---- the finalize as the PROLOGUE of its consumer (sfk_bn_finalize_apply, sfk_bn_bwd_finalize_apply).
+// The step's 174 finalize launches are 8 us kernels on dependent chains, each behind a dispatch gap: with them skipped by the
+// scheduler the step ran 26.4 instead of 27.5 ms.  Here the consumer's FIRST workgroups (dispatch order = linear block id, so
+// whenever any workgroup is resident they are resident or finished: no deadlock) fold the channel pairs -- the same
+// deterministic block sums as the stand-alone kernel -- release their results (fence, then a counter), and every workgroup
+// waits for the counter before it reads the coefficients: the fold runs under the dispatch ramp of the consumer's own grid.
+// The last workgroup to leave zeroes both counters for the next launch.
+template <class Pair>
+__device__ __forceinline__ void bn_fused_prologue(int* sync, int npairs, Pair&& do_pair) {
+  const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+  const int nfin = npairs < nblk ? npairs : nblk;
+  if (bid < nfin) {
+    for (int p = bid; p < npairs; p += nfin) {
+      do_pair(p);
+      __syncthreads();                                  // (block_sum_partials' LDS is reused by the next pair)
+    }
+    __threadfence();                                    // this thread's results are visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sync[0], 1);       // ... before the count says so
+  }
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfin) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __threadfence();                                      // acquire: the coefficient loads below see the folded values
+}
+__device__ __forceinline__ void bn_fused_epilogue(int* sync) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nblk = gridDim.x * gridDim.y;
+    if (atomicAdd(&sync[1], 1) == nblk - 1) {           // everybody is past the wait: reset for the next launch
+      sync[0] = 0;
+      sync[1] = 0;
+      __threadfence();
+    }
   }
 }
 
@@ -273,10 +324,10 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // SUMS: the block also leaves the column sums of what it STORED as one partial row [c][2] = (sum a, 0) -- the fused block
 // tail takes g = 1^T a from these (sfk_bn_tail_fwd) instead of a constant-1 channel group beside every pixel.
 template <typename T, int RES, bool RELU, int NT, bool SUMS = false>
-__global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
-                                                       const float* scale, const float* shift,
-                                                       const float* rscale, const float* rshift, uint8_t* relu_bits,
-                                                       float* sums = nullptr) {
+__device__ __forceinline__ void bn_apply_body(FM y, FM res, FM out, int64_t pixels, int c,
+                                              const float* scale, const float* shift,
+                                              const float* rscale, const float* rshift, uint8_t* relu_bits,
+                                              float* sums = nullptr) {
   constexpr int nt = NT;   // compile time: a run-time choice between the two access flavours is merged into plain accesses
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
@@ -284,7 +335,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
   float asum[VEC], zsum[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { asum[i] = 0.f; zsum[i] = 0.f; }
-  if (!SUMS && !cm.active) return;
   if (cm.active) {
   float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
   load_coef<VEC>(sc, scale, cm.cg);
@@ -337,6 +387,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int
   }
   }
   if (SUMS) block_reduce_store<VEC>(cm, cgs, asum, zsum, sums, c);
+}
+
+template <typename T, int RES, bool RELU, int NT, bool SUMS = false>
+__global__ __launch_bounds__(256) void bn_apply_kernel(FM y, FM res, FM out, int64_t pixels, int c,
+                                                       const float* scale, const float* shift,
+                                                       const float* rscale, const float* rshift, uint8_t* relu_bits,
+                                                       float* sums = nullptr) {
+  bn_apply_body<T, RES, RELU, NT, SUMS>(y, res, out, pixels, c, scale, shift, rscale, rshift, relu_bits, sums);
+}
+
+// the apply with its BatchNorm's finalize as the prologue (scale / shift of `fin` are the ones the body reads)
+template <typename T, int RES, bool RELU, int NT>
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(FM y, FM res, FM out, int64_t pixels, int c,
+                                                           const float* rscale, const float* rshift, uint8_t* relu_bits,
+                                                           const FinK fin) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && fin.nbt) fin.nbt[0] += 1;
+  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_finalize_pair(fin, p); });
+  bn_apply_body<T, RES, RELU, NT, false>(y, res, out, pixels, c, fin.scale, fin.shift, rscale, rshift, relu_bits, nullptr);
+  bn_fused_epilogue(fin.sync);
 }
 
 // ------------------------------------------------------------------ backward
@@ -415,31 +484,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(FM da, FM y, FM msrc
   block_reduce_store<VEC>(cm, cgs, s1, s2, partials, c);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, int c,
-                                                              double count, const float* gamma,
-                                                              const float* invstd, float* dgamma, float* dbeta,
-                                                              float* coef) {
-  const int ch = blockIdx.x * 2 + (threadIdx.x & 1);
+struct BFinK {
+  const float* partials;
+  int nparts, c;
+  double count;
+  const float* gamma; const float* invstd;
+  float* dgamma; float* dbeta; float* coef;
+  int* sync;
+};
+
+__device__ __forceinline__ void bn_bwd_finalize_pair(const BFinK& f, int pair) {
+  const int ch = pair * 2 + (threadIdx.x & 1);
   double s1, s2;
-  block_sum_partials(partials, nparts, c, blockIdx.x * 2, s1, s2);
+  block_sum_partials(f.partials, f.nparts, f.c, pair * 2, s1, s2);
   if (threadIdx.x > 1) return;
-  if (dgamma) dgamma[ch] += (float)s2;
-  if (dbeta) dbeta[ch] += (float)s1;
-  coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
-  coef[ch * 3 + 1] = (float)(s1 / count);
-  coef[ch * 3 + 2] = (float)(s2 / count);
+  if (f.dgamma) f.dgamma[ch] += (float)s2;
+  if (f.dbeta) f.dbeta[ch] += (float)s1;
+  f.coef[ch * 3 + 0] = f.gamma[ch] * f.invstd[ch];
+  f.coef[ch * 3 + 1] = (float)(s1 / f.count);
+  f.coef[ch * 3 + 2] = (float)(s2 / f.count);
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BFinK f) { bn_bwd_finalize_pair(f, blockIdx.x); }
+
 template <typename T, int MASK, int NT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
-                                                           const float* mean, const float* invstd,
-                                                           const float* scale, const float* shift,
-                                                           const float* coef) {
+__device__ __forceinline__ void bn_bwd_apply_body(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
+                                                  const float* mean, const float* invstd,
+                                                  const float* scale, const float* shift,
+                                                  const float* coef) {
   constexpr int nt = NT;
   constexpr int VEC = DT<T>::VEC;
   const int cgs = c / VEC;
   const ChanMap cm(cgs);
-  if (!cm.active) return;
+  if (!cm.active) return;                      // (a thread, not the workgroup: the callers' barriers come before / after)
   float mu[VEC], is[VEC], sc[VEC], sh[VEC], c0[VEC], c1[VEC], c2[VEC];
   load_coef<VEC>(mu, mean, cm.cg);
   load_coef<VEC>(is, invstd, cm.cg);
@@ -493,6 +570,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc,
       else o.store(op + p * dyo.ld);
     }
   }
+}
+
+template <typename T, int MASK, int NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
+                                                           const float* mean, const float* invstd,
+                                                           const float* scale, const float* shift,
+                                                           const float* coef) {
+  bn_bwd_apply_body<T, MASK, NT>(da, y, msrc, dyo, pixels, c, mean, invstd, scale, shift, coef);
+}
+
+template <typename T, int MASK, int NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
+                                                               const float* mean, const float* scale, const float* shift,
+                                                               const BFinK fin) {
+  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_bwd_finalize_pair(fin, p); });
+  bn_bwd_apply_body<T, MASK, NT>(da, y, msrc, dyo, pixels, c, mean, fin.invstd, scale, shift, fin.coef);
+  bn_fused_epilogue(fin.sync);
 }
 
 // ------------------------------------------------------------------ stem tail backward: MaxPool (1,3,3)/(1,2,2)/(0,1,1) + ReLU + BN
@@ -649,9 +743,9 @@ extern "C" int sfk_bn_finalize(const float* partials, int32_t nparts, int32_t c,
   if ((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) return SFK_ERR_INVALID;   // rows are read as float4
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c / 2), dim3(256), 0, s, partials,
-                     nparts, c, (double)count, gamma, beta, eps, momentum, running_mean, running_var,
-                     num_batches_tracked, mean, invstd, scale, shift);
+  const FinK f{partials, nparts, c, (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+               mean, invstd, scale, shift, nullptr};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c / 2), dim3(256), 0, s, f);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -717,6 +811,58 @@ extern "C" int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* 
   return y->dtype == SFK_BF16
              ? launch_apply<bf16_t>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, out_sums, max_parts, nparts_out, s)
              : launch_apply<float>(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits, out_sums, max_parts, nparts_out, s);
+}
+
+namespace {
+template <typename T>
+int launch_apply_fin(const sfk_fmap* y, const sfk_fmap* res, const float* rs, const float* rb, int relu, const sfk_fmap* out,
+                     uint8_t* bits, const FinK& fin, hipStream_t s) {
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np);
+  const dim3 blk(256);
+  grid.x = span_blocks(y->c / DT<T>::VEC, px);
+  const FM fy = fm_of(y), fr = fm_of(res), fo = fm_of(out);
+  const int mode = !res ? 0 : (rs ? 2 : 1);
+  const int nt = nt_hint(y, sfk_tune().nt_apply_mb, 3);
+#define SFK_APPLY_FIN(R, A)                                                                                              \
+  do {                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((bn_apply_fin_kernel<T, R, A, 3>), grid, blk, 0, s, fy, fr, fo, px, y->c, rs, rb, bits, fin); \
+    else hipLaunchKernelGGL((bn_apply_fin_kernel<T, R, A, 0>), grid, blk, 0, s, fy, fr, fo, px, y->c, rs, rb, bits, fin);    \
+  } while (0)
+  if (relu) {
+    if (mode == 0) SFK_APPLY_FIN(0, true); else if (mode == 1) SFK_APPLY_FIN(1, true); else SFK_APPLY_FIN(2, true);
+  } else {
+    if (mode == 0) SFK_APPLY_FIN(0, false); else if (mode == 1) SFK_APPLY_FIN(1, false); else SFK_APPLY_FIN(2, false);
+  }
+#undef SFK_APPLY_FIN
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+}  // namespace
+
+extern "C" int sfk_bn_finalize_apply(const float* partials, int32_t nparts, int64_t count, const float* gamma, const float* beta,
+                                     float eps, float momentum, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, float* mean, float* invstd, float* workspace, int32_t* sync,
+                                     const sfk_fmap* y, float* scale, float* shift, const sfk_fmap* res, const float* res_scale,
+                                     const float* res_shift, int32_t relu, const sfk_fmap* out, uint8_t* relu_bits,
+                                     sfk_stream_t stream) {
+  if (!sfk_fmap_ok(y) || !partials || nparts <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift || !sync)
+    return SFK_ERR_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SFK_ERR_INVALID;
+  if (relu_bits && !relu) return SFK_ERR_INVALID;
+  if (!sfk_fmap_ok(out) || !same_shape(y, out)) return SFK_ERR_INVALID;
+  if (res && (!sfk_fmap_ok(res) || !same_shape(y, res))) return SFK_ERR_INVALID;
+  if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res)) || (y->c & 1)) return SFK_ERR_UNSUPPORTED;
+  if (((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) || (((uintptr_t)sync) & 3)) return SFK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rows = nparts;
+  partials = fold_partials(partials, nparts, y->c, workspace, &rows, s);
+  const FinK fin{partials, rows, y->c, (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                 mean, invstd, scale, shift, sync};
+  return y->dtype == SFK_BF16 ? launch_apply_fin<bf16_t>(y, res, res_scale, res_shift, relu, out, relu_bits, fin, s)
+                              : launch_apply_fin<float>(y, res, res_scale, res_shift, relu, out, relu_bits, fin, s);
 }
 
 namespace {
@@ -812,8 +958,8 @@ extern "C" int sfk_bn_bwd_finalize(const float* partials, int32_t nparts, int32_
   if ((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) return SFK_ERR_INVALID;   // rows are read as float4
   hipStream_t s = static_cast<hipStream_t>(stream);
   partials = fold_partials(partials, nparts, c, workspace, &nparts, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 2), dim3(256), 0, s,
-                     partials, nparts, c, (double)count, gamma, invstd, dgamma, dbeta, coef);
+  const BFinK f{partials, nparts, c, (double)count, gamma, invstd, dgamma, dbeta, coef, nullptr};
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c / 2), dim3(256), 0, s, f);
   SFK_CHECK_LAUNCH();
   return SFK_OK;
 }
@@ -829,6 +975,48 @@ extern "C" int sfk_bn_bwd_apply(const sfk_fmap* da, const sfk_fmap* y, const sfk
   return y->dtype == SFK_BF16
              ? launch_bwd_apply<bf16_t>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s)
              : launch_bwd_apply<float>(da, y, mask_src, mean, invstd, scale, shift, relu, coef, dy, s);
+}
+
+namespace {
+template <typename T>
+int launch_bwd_apply_fin(const sfk_fmap* da, const sfk_fmap* y, const sfk_fmap* ms, const float* mean, const float* scale,
+                         const float* shift, int relu, const sfk_fmap* dy, const BFinK& fin, hipStream_t s) {
+  const int64_t px = sfk_fmap_pixels(y);
+  int np;
+  dim3 grid = chan_grid(y->c / DT<T>::VEC, px, 0, &np);
+  const dim3 blk(256);
+  grid.x = span_blocks(y->c / DT<T>::VEC, px);
+  const FM a = fm_of(da), b = fm_of(y), m = fm_of(ms), o = fm_of(dy);
+  const int mask = ms ? 2 : (relu ? 1 : 0);
+  const int nt = nt_hint(y, sfk_tune().nt_bwd_apply_mb, 3);
+#define SFK_APP_FIN(M)                                                                                                     \
+  do {                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, M, 3>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, scale, shift, fin); \
+    else hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<T, M, 0>), grid, blk, 0, s, a, b, m, o, px, y->c, mean, scale, shift, fin);    \
+  } while (0)
+  if (mask == 0) SFK_APP_FIN(0); else if (mask == 1) SFK_APP_FIN(1); else SFK_APP_FIN(2);
+#undef SFK_APP_FIN
+  SFK_CHECK_LAUNCH();
+  return SFK_OK;
+}
+}  // namespace
+
+extern "C" int sfk_bn_bwd_finalize_apply(const float* partials, int32_t nparts, int64_t count, const float* gamma, float* dgamma,
+                                         float* dbeta, float* coef, float* workspace, int32_t* sync, const sfk_fmap* da,
+                                         const sfk_fmap* y, const sfk_fmap* mask_src, const float* mean, const float* invstd,
+                                         const float* scale, const float* shift, int32_t relu, const sfk_fmap* dy,
+                                         sfk_stream_t stream) {
+  const int st = check_bwd(da, y, mask_src, mean, invstd, scale, shift, relu);
+  if (st != SFK_OK) return st;
+  if (!partials || nparts <= 0 || count <= 0 || !gamma || !coef || !sync || !sfk_fmap_ok(dy) || !same_shape(da, dy)) return SFK_ERR_INVALID;
+  if (!sfk_fmap_vec_ok(dy) || (y->c & 1)) return SFK_ERR_UNSUPPORTED;
+  if (((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) || (((uintptr_t)sync) & 3)) return SFK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rows = nparts;
+  partials = fold_partials(partials, nparts, y->c, workspace, &rows, s);
+  const BFinK fin{partials, rows, y->c, (double)count, gamma, invstd, dgamma, dbeta, coef, sync};
+  return y->dtype == SFK_BF16 ? launch_bwd_apply_fin<bf16_t>(da, y, mask_src, mean, scale, shift, relu, dy, fin, s)
+                              : launch_bwd_apply_fin<float>(da, y, mask_src, mean, scale, shift, relu, dy, fin, s);
 }
 
 // ---- stem tail backward (see bn_pool_bwd_kernel): only the stems' (3, 2, 1) pool

@@ -149,6 +149,7 @@ class EngineOptions:
     trunk_priority: bool = True        # the trunk lane on a high-priority HIP stream (TrainStep)
     mfma_wgrad_trunk: bool = False     # MFMA-bound filter gradients on the pathway's own lane, directly behind their data gradient
     dist_wgrad_one_lane: bool = True   # world > 1: all filter gradients on ONE lane, the collective's stream is the fourth queue
+    fuse_finalize: bool = True         # BatchNorm finalize as the prologue of its bn_apply / bn_bwd_apply launch (sfk_bn_finalize_apply)
     lane_cus: str = ""                 # EXPERIMENT: CUs the side lanes may use, "fast,wgrad_slow,wgrad_fast" (0 / empty = all): the
                                        # side streams are created with hipExtStreamCreateWithCUMask (eager schedule only)
     ablate_kinds: frozenset = frozenset()
@@ -160,7 +161,7 @@ class EngineOptions:
             "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"),
             "SFK_SPLIT_ADAM": ("split_adam", "!0"), "SFK_TRUNK_PRIO": ("trunk_priority", "!0"),
             "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0"),
-            "SFK_LANE_CUS": ("lane_cus", "s")}
+            "SFK_LANE_CUS": ("lane_cus", "s"), "SFK_FUSE_FIN": ("fuse_finalize", "!0")}
 
     @classmethod
     def from_env(cls, env=None) -> "EngineOptions":
@@ -214,6 +215,7 @@ class Engine:
         self._layers: Dict[str, _Layer] = {}
         self._bufs: Dict[str, torch.Tensor] = {}
         self._plans: Dict[tuple, Plan] = {}
+        self._pending_fin: Dict[int, tuple] = {}     # deferred BatchNorm finalizes by id(scale buffer): consumed by the next _apply
         self._build_params(seed)
         self.max_parts = _max_parts() if getattr(self.be, "name", "") == "hip" else 1024
         self.two_streams = True           # slow / fast pathway on two HIP streams (see OpList)
@@ -474,8 +476,9 @@ class Engine:
                       bytes=float(esz * (x.pixels * L.eg.cin + rows * L.eg.cout + L.w_numel)))
         return stats, mt
 
-    def _unit_fwd(self, pl: Plan, L: _Layer, x: FMap, tag: str, train: bool, n: int):
-        """conv + BatchNorm coefficients.  returns (y, scale, shift, rec)"""
+    def _unit_fwd(self, pl: Plan, L: _Layer, x: FMap, tag: str, train: bool, n: int, defer: bool = False):
+        """conv + BatchNorm coefficients.  returns (y, scale, shift, rec).  defer: the caller's next op is _apply(y, scale, shift,
+        ...) on the same lane -- the finalize then rides that launch as its prologue (EngineOptions.fuse_finalize)"""
         od = L.eg.out_dims((x.t, x.h, x.w))
         y = self._fmap(f"y.{tag}", n, od[0], od[1], od[2], L.c)
         scale = self._buf(f"scale.{tag}", L.c, torch.float32)
@@ -486,9 +489,13 @@ class Engine:
             stats, mt = self._conv(pl, L, x, y, f"stats.{tag}")
             mean = self._buf(f"mean.{tag}", L.c, torch.float32)
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
-            pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
-                                              self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
-                                              self._fold_ws(tag, L.c)), kind="bn_finalize")
+            if defer and self.options.fuse_finalize and hasattr(self.be, "bn_finalize_apply"):
+                self._pending_fin[id(scale)] = (stats, mt, y.pixels, gamma, beta, self.spec.bn_eps, self.spec.bn_momentum, L.rm, L.rv,
+                                                L.nbt, mean, invstd, self._fold_ws(tag, L.c), self._buf(f"finsync.{tag}", 2, torch.int32))
+            else:
+                pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
+                                                  self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
+                                                  self._fold_ws(tag, L.c)), kind="bn_finalize")
             rec = _UnitRec(L, x, y, mean, invstd, scale, shift)
         else:
             self._conv(pl, L, x, y, None)
@@ -497,7 +504,12 @@ class Engine:
 
     def _apply(self, pl: Plan, y: FMap, scale, shift, res, res_scale, res_shift, relu: bool, out: FMap, bits=None):
         esz = 2 if self.dtype == torch.bfloat16 else 4
-        pl.fwd.append(self.be.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=bits),
+        fin = self._pending_fin.pop(id(scale), None)
+        if fin is not None:     # this BatchNorm's finalize was deferred to here (_unit_fwd(defer=True)): one launch for both
+            run = self.be.bn_finalize_apply(*fin, y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=bits)
+        else:
+            run = self.be.bn_apply(y, scale, shift, res, res_scale, res_shift, relu, out, relu_bits=bits)
+        pl.fwd.append(run,
                       kind="bn_apply",
                       bytes=float(y.pixels * y.c * esz * (2 + (1 if res is not None else 0))
                                   + (y.pixels * y.c // self.kvec if bits is not None else 0)))
@@ -525,6 +537,18 @@ class Engine:
             pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
                           bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0))
                           + (rec.y.pixels * L.c // self.kvec if bits is not None else 0))
+        if self.options.fuse_finalize and hasattr(self.be, "bn_bwd_finalize_apply"):
+            # the finalize rides the apply launch as its prologue (sfk_bn_bwd_finalize_apply): dgamma / dbeta are complete behind it
+            fin = (parts, np_, rec.y.pixels, self._pslice(L.g_off, L.c), self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
+                   self._fold_ws(tag, L.c), self._buf(f"bfinsync.{tag}", 2, torch.int32))
+            if dz_inplace:   # the mask is already applied to da
+                run, nb = self.be.bn_bwd_finalize_apply(*fin, da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False, dy), 3
+            else:
+                run = self.be.bn_bwd_finalize_apply(*fin, da, rec.y, mask_src, rec.mean, rec.invstd, rec.scale, rec.shift, relu, dy)
+                nb = 3 + (1 if mask_src is not None else 0)
+            pl.bwd.append(run, kind="bn_bwd_apply", layer=L.cb.norm_key, bytes=el * nb)
+            pl.grad_marks.append((len(pl.bwd), (L.g_off, L.b_off + round_up(L.c, self.vec) - L.g_off)))
+            return
         pl.bwd.append(self.be.bn_bwd_finalize(parts, np_, L.c, rec.y.pixels, self._pslice(L.g_off, L.c), rec.invstd,
                                               self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
                                               self._fold_ws(tag, L.c)), kind="bn_finalize")
@@ -731,7 +755,7 @@ class Engine:
     # ---- lateral fusion: conv over the fast pathway -> BN -> ReLU -> channel slice of the slow buffer
     def _fusion_fwd(self, pl, bi: int, xf: FMap, out_slice: FMap, train: bool):
         L = self._layers[self.wiring.fusions[bi].conv_key]
-        y, scale, shift, rec = self._unit_fwd(pl, L, xf, f"fuse{bi}", train, xf.n)
+        y, scale, shift, rec = self._unit_fwd(pl, L, xf, f"fuse{bi}", train, xf.n, defer=True)
         assert (y.t, y.h, y.w, y.c) == (out_slice.t, out_slice.h, out_slice.w, out_slice.c), \
             "lateral fusion: fast pathway does not line up with the slow pathway (T_fast / stride != T_slow?)"
         self._apply(pl, y, scale, shift, None, None, None, True, out_slice)
@@ -905,10 +929,10 @@ class Engine:
                 pl.fwd.cur_lane = sl
             y1, s1, h1, rec1 = self._unit_fwd(pl, L1, x, f"{tag}.b1", train, n)
             pl.fwd.cur_lane = home
-        ya, sa, ha, reca = self._unit_fwd(pl, La, x, f"{tag}.a", train, n)
+        ya, sa, ha, reca = self._unit_fwd(pl, La, x, f"{tag}.a", train, n, defer=True)
         aa = self._fmap(f"a.{tag}.a", n, ya.t, ya.h, ya.w, La.c)
         self._apply(pl, ya, sa, ha, None, None, None, True, aa)
-        yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n)
+        yb, sb, hb, recb = self._unit_fwd(pl, Lb, aa, f"{tag}.b", train, n, defer=not self._tail_ok(Lc))
         if sl is not None:
             pl.fwd.sync(pl.fwd.cur_lane, sl)          # the shortcut map and its coefficients are ready
         if self._tail_ok(Lc):
@@ -918,7 +942,7 @@ class Engine:
             return (blk, tag, x, out, rec1, reca, recb, tail, bits)
         ab = self._fmap(f"a.{tag}.b", n, yb.t, yb.h, yb.w, Lb.c)
         self._apply(pl, yb, sb, hb, None, None, None, True, ab)
-        yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n)
+        yc, sc, hc, recc = self._unit_fwd(pl, Lc, ab, f"{tag}.c", train, n, defer=True)
         assert (yc.t, yc.h, yc.w, yc.c) == (out.t, out.h, out.w, out.c)
         # the block output's ReLU mask, 1 bit per element, for the backward pass (which otherwise re-reads `out`)
         bits = self._buf(f"relubits.{tag}", out.pixels * (out.c // self.kvec), torch.uint8) if (train and self.relu_bits) else None
@@ -1216,6 +1240,7 @@ class Engine:
             if len(self._plans) >= 6:
                 self._plans.clear()
             pl = self._build_plan(x_slow, x_fast, slow_t_index, train)
+            assert not self._pending_fin, "a deferred BatchNorm finalize was never consumed by an _apply"
             pl.key = key
             Engine._plan_serial += 1
             pl.serial = Engine._plan_serial          # never reused (id() of a dropped plan can be)
