@@ -39,9 +39,9 @@ extern "C" {
  * (tools/abi_lock.py refuses to re-lock the same version).  History: 10 = struct_size handshake in the descriptor structs; 11 = sfk_conv_wgrad_wants_workspace,
  * sfk_tuning.wgrad_target_256 / wgrad_min_stages_256 (retired in 15); 12 = sfk_bn_apply(out_sums), sfk_bn_tail_fwd / _bwd take the column sums
  * of `a` from it (no constant-1 channel group beside the activation any more); 13 = sfk_conv_pw_dual; 14 = sfk_tuning.igemm_p8 / wgrad_p8,
- * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band; 17 = sfk_tuning.stem_v3; 18 = sfk_bn_finalize_apply,
+ * sfk_conv_igemm_family value 4; 15 = sfk_tuning.igemm_halo, family value 5; 16 = sfk_tuning.wgrad_band; 17 = sfk_tuning.stem_v3; 18 = sfk_bn_finalize_apply (19, 20: SFK_BN_SYNC_INTS counters),
  * sfk_bn_bwd_finalize_apply. */
-#define SFK_ABI_VERSION 18
+#define SFK_ABI_VERSION 20
 #define SFK_MAX_TAPS 16
 #define SFK_BN_FOLD_ROWS 64 /* rows of the optional BatchNorm fold workspace */
 
@@ -275,8 +275,9 @@ int sfk_bn_apply(const sfk_fmap* y, const float* scale, const float* shift, cons
  * sums: results bit-identical to the two calls), every workgroup waits for their counter before it reads scale / shift.  The
  * step's finalize launches are 8 us kernels on dependent chains behind a dispatch gap each; as a prologue the fold runs under
  * the dispatch ramp of the consumer's own grid.  Arguments as the two calls (c = y->c; out_sums is not available here);
- * sync: 2 int32 of the caller's, ZERO before the first call and left zero by every call (one pair per BatchNorm that may be in
- * flight at the same time). */
+ * sync: SFK_BN_SYNC_INTS int32 of the caller's, ZERO before the first call and left zero by every call (one set per BatchNorm that
+ * may be in flight at the same time).  Meant for c <= 512: the channel pairs are claimed through one counter. */
+#define SFK_BN_SYNC_INTS 2144
 int sfk_bn_finalize_apply(const float* partials, int32_t nparts, int64_t count, const float* gamma, const float* beta,
                           float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           float* mean, float* invstd, float* workspace, int32_t* sync, const sfk_fmap* y, float* scale,

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(_lib._FMap) == 40            # void* + 8 x int32
     assert ctypes.sizeof(_lib._Tap) == 4
     assert _lib._ConvDesc.taps.size == 4 * _lib.SFK_MAX_TAPS
-    assert lib.sfk_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.sfk_abi_version() == _lib.ABI_VERSION == 20
     assert lib.sfk_status_string(0) == b"ok" and lib.sfk_status_string(-2).startswith(b"unsupported")
 
 

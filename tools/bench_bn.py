@@ -36,3 +36,24 @@ for name, (run, units) in ops.items():
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
     print(f"px {px} c {c} ld_out {old}: {name:11s} {us:7.1f} us  {units * px * c * 2 / us / 1e6:6.2f} TB/s", flush=True)
+# finalize + apply as two launches against the fused launch (sfk_bn_finalize_apply); partial rows as a conv epilogue leaves them
+nparts = max(1, min(4096, px // 256))
+stats = torch.rand(nparts * c * 2, device=dev)
+gamma, beta = v(), v() - 1.0
+rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+sync = torch.zeros(2144, dtype=torch.int32, device=dev)
+fin = be.bn_finalize(stats, nparts, c, px, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, invstd, scale, shift)
+app = be.bn_apply(y, scale, shift, None, None, None, True, out)
+fused = be.bn_finalize_apply(stats, nparts, px, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, invstd, None, sync, y, scale, shift, None, None,
+                             None, True, out)
+for name, runs in (("finalize+apply", (fin, app)), ("fused", (fused,))):
+    for _ in range(3):
+        for r in runs: r(st)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(20):
+        for r in runs: r(st)
+    b.record()
+    torch.cuda.synchronize()
+    print(f"px {px} c {c} rows {nparts}: {name:15s} {a.elapsed_time(b) / 20 * 1e3:7.1f} us", flush=True)

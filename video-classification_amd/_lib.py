@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFK_LIB") or os.path.join(HERE, "libsfk.so")   # SFK_LIB: experiment builds (tools/gpu_ab_lib.sh)
 SFK_F32, SFK_BF16 = 0, 1
 SFK_MAX_TAPS = 16
-ABI_VERSION = 18       # include/sfk.h SFK_ABI_VERSION
+BN_SYNC_INTS = 2144       # include/sfk.h SFK_BN_SYNC_INTS
+ABI_VERSION = 20       # include/sfk.h SFK_ABI_VERSION
 BN_FOLD_ROWS = 64      # include/sfk.h SFK_BN_FOLD_ROWS
 _DT = {torch.float32: SFK_F32, torch.bfloat16: SFK_BF16}
 
@@ -526,10 +527,10 @@ class HipBackend:
     def bn_finalize_apply(self, partials, nparts, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd,
                           workspace, sync, y: FMap, scale, shift, res: Optional[FMap], res_scale, res_shift, relu: bool, out: FMap,
                           relu_bits=None):
-        """bn_finalize + bn_apply in one launch (sfk_bn_finalize_apply); sync: 2 zeroed int32 of this BatchNorm's own"""
+        """bn_finalize + bn_apply in one launch (sfk_bn_finalize_apply); sync: BN_SYNC_INTS zeroed int32 of this BatchNorm's own"""
         fy, fo = _c_fmap(y), _c_fmap(out)
         fr = _c_fmap(res) if res is not None else None
-        assert sync.dtype == torch.int32 and sync.numel() >= 2
+        assert sync.dtype == torch.int32 and sync.numel() >= BN_SYNC_INTS
         ts = (partials, gamma, beta, running_mean, running_var, nbt, mean, invstd, workspace, sync, fy, fo, fr, y, out, res, scale, shift,
               res_scale, res_shift, relu_bits)
         return self._plain("sfk_bn_finalize_apply", _ptr(partials), nparts, count, _ptr(gamma), _ptr(beta), eps, momentum,
@@ -542,7 +543,7 @@ class HipBackend:
         """bn_bwd_finalize + bn_bwd_apply in one launch (sfk_bn_bwd_finalize_apply)"""
         fa, fy, fo = _c_fmap(da), _c_fmap(y), _c_fmap(dy)
         fm = _c_fmap(mask_src) if mask_src is not None else None
-        assert sync.dtype == torch.int32 and sync.numel() >= 2
+        assert sync.dtype == torch.int32 and sync.numel() >= BN_SYNC_INTS
         ts = (partials, gamma, dgamma, dbeta, coef, workspace, sync, fa, fy, fo, fm, da, y, dy, mask_src, mean, invstd, scale, shift)
         return self._plain("sfk_bn_bwd_finalize_apply", _ptr(partials), nparts, count, _ptr(gamma), _ptr(dgamma), _ptr(dbeta), _ptr(coef),
                            _ptr(workspace), _ptr(sync), C.byref(fa), C.byref(fy), C.byref(fm) if fm else None, _ptr(mean), _ptr(invstd),

@@ -63,10 +63,14 @@ inline dim3 chan_grid(int cgs, int64_t pixels, int max_parts, int* nparts) {
   return dim3((unsigned)parts, (unsigned)cchunks);
 }
 
-template <int VEC>
+// COH: device-coherent loads (agent-scope atomics) -- the values were written by OTHER workgroups of this launch (the fused
+// finalize prologue) and an acquire fence per workgroup would invalidate the L2 thousands of times per launch (first build of
+// sfk_bn_finalize_apply: 900 us against 40)
+template <int VEC, bool COH = false>
 __device__ __forceinline__ void load_coef(float (&dst)[VEC], const float* src, int cg) {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) dst[i] = src[cg * VEC + i];
+  for (int i = 0; i < VEC; ++i)
+    dst[i] = COH ? __hip_atomic_load(src + cg * VEC + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[cg * VEC + i];
 }
 
 // block-level reduction of per-thread (a[VEC], b[VEC]) over the threads that share a channel group.  The threads' values
@@ -240,9 +244,19 @@ struct FinK {
   float* running_mean; float* running_var;
   int64_t* nbt;
   float* mean; float* invstd; float* scale; float* shift;
-  int* sync;                   // [2] zero before the first launch: finalize workgroups done, workgroups that left
+  int* sync;                   // [SFK_FIN_SYNC_INTS] zero before the first launch (counters of bn_fused_prologue / _epilogue)
 };
 
+// COH: the results go out as device-coherent (write-through) stores -- the fused launches' readers are other workgroups of the
+// SAME launch, and a release FENCE per folding workgroup writes that XCD's whole L2 back (measured: 0.23 us per channel pair,
+// serialised, while the apply's own output lines are dirty)
+template <bool COH>
+__device__ __forceinline__ void st_coef(float* p, float v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <bool COH = false>
 __device__ __forceinline__ void bn_finalize_pair(const FinK& f, int pair) {
   const int ch = pair * 2 + (threadIdx.x & 1);         // c is a multiple of 2 (checked by the callers)
   double s1, s2;
@@ -253,10 +267,10 @@ __device__ __forceinline__ void bn_finalize_pair(const FinK& f, int pair) {
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)f.eps));
   const float sc = f.gamma[ch] * is;
-  f.mean[ch] = (float)mu;
-  f.invstd[ch] = is;
-  f.scale[ch] = sc;
-  f.shift[ch] = f.beta[ch] - (float)mu * sc;
+  st_coef<COH>(f.mean + ch, (float)mu);
+  st_coef<COH>(f.invstd + ch, is);
+  st_coef<COH>(f.scale + ch, sc);
+  st_coef<COH>(f.shift + ch, f.beta[ch] - (float)mu * sc);
   if (f.running_mean) {
     const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
     f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * (float)mu;
@@ -271,38 +285,64 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FinK f) {
 
 // ---- the finalize as the PROLOGUE of its consumer (sfk_bn_finalize_apply, sfk_bn_bwd_finalize_apply).
 // The step's 174 finalize launches are 8 us kernels on dependent chains, each behind a dispatch gap: with them skipped by the
-// scheduler the step ran 26.4 instead of 27.5 ms.  Here the consumer's FIRST workgroups (dispatch order = linear block id, so
-// whenever any workgroup is resident they are resident or finished: no deadlock) fold the channel pairs -- the same
+// scheduler the step ran 26.4 instead of 27.5 ms.  Here the consumer's first workgroups to run fold the channel pairs -- the same
 // deterministic block sums as the stand-alone kernel -- release their results (fence, then a counter), and every workgroup
 // waits for the counter before it reads the coefficients: the fold runs under the dispatch ramp of the consumer's own grid.
-// The last workgroup to leave zeroes both counters for the next launch.
+// The last workgroup to leave zeroes the counters for the next launch.
+constexpr int SFK_FIN_MAX_C = 512;                // widest BatchNorm the fused launches take (coefficients staged in LDS, pairs claimed one by one)
+constexpr int SFK_FIN_GROUPS = 64;              // leave counters (sync[3 ..]): a read-modify-write on ONE address costs ~60 ns from any XCD
+// every counter on its own 128-byte line: atomics on ONE line serialise (~25 ns each, whatever the address inside it)
+constexpr int SFK_FIN_LINE = 32, SFK_FIN_DONE = 0, SFK_FIN_CLAIM = SFK_FIN_LINE, SFK_FIN_TOP = 2 * SFK_FIN_LINE, SFK_FIN_LEAVE = 3 * SFK_FIN_LINE;
+constexpr int SFK_FIN_SYNC_INTS = SFK_FIN_LEAVE + SFK_FIN_GROUPS * SFK_FIN_LINE;
+static_assert(SFK_FIN_SYNC_INTS == SFK_BN_SYNC_INTS, "include/sfk.h");
+
 template <class Pair>
 __device__ __forceinline__ void bn_fused_prologue(int* sync, int npairs, Pair&& do_pair) {
-  const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-  const int nfin = npairs < nblk ? npairs : nblk;
-  if (bid < nfin) {
-    for (int p = bid; p < npairs; p += nfin) {
+  // Channel pairs are CLAIMED (one counter) by running workgroups, not assigned by block id: with the other lanes' kernels on the
+  // chip fewer workgroups than pairs may be resident, and a workgroup that waits for a pair owned by one that cannot be
+  // dispatched until somebody leaves never leaves (first build: the step hung).  Only the first 2 npairs workgroups claim
+  // (dispatch is in block order, so whenever anybody is resident some of them are running or done; 2,000 workgroups starting
+  // together would otherwise queue 2,000 atomics on one address at ~60 ns each), and a workgroup only waits after the claim
+  // counter passed npairs, i.e. every pair is in the hands of a RUNNING workgroup.
+  __shared__ int s_pair;
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+  int mine = 0;
+  if (bid < 2 * npairs) {
+    for (;;) {
+      if (threadIdx.x == 0)
+        s_pair = __hip_atomic_load(&sync[SFK_FIN_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= npairs ? npairs : atomicAdd(&sync[SFK_FIN_CLAIM], 1);
+      __syncthreads();
+      const int p = s_pair;
+      __syncthreads();                                  // (s_pair and block_sum_partials' LDS are reused)
+      if (p >= npairs) break;
       do_pair(p);
-      __syncthreads();                                  // (block_sum_partials' LDS is reused by the next pair)
+      ++mine;
     }
-    __threadfence();                                    // this thread's results are visible device-wide ...
+  }
+  if (mine) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's coherent stores are acknowledged (no fence: see st_coef) ...
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sync[0], 1);       // ... before the count says so
+    if (threadIdx.x == 0) atomicAdd(&sync[SFK_FIN_DONE], mine);    // ... before the count says so
   }
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfin) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(&sync[SFK_FIN_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < npairs) __builtin_amdgcn_s_sleep(2);
   }
-  __syncthreads();
-  __threadfence();                                      // acquire: the coefficient loads below see the folded values
+  __syncthreads();                                      // (no acquire fence: the consumers read the coefficients with coherent loads)
 }
+// every workgroup reports that it is past the wait -- on one of 64 counters (6,000 workgroups on ONE counter cost 400 us); the
+// workgroup that completes a counter reports to sync[1], the one that completes that zeroes everything for the next launch
 __device__ __forceinline__ void bn_fused_epilogue(int* sync) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int nblk = gridDim.x * gridDim.y;
-    if (atomicAdd(&sync[1], 1) == nblk - 1) {           // everybody is past the wait: reset for the next launch
-      sync[0] = 0;
-      sync[1] = 0;
-      __threadfence();
+    const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int grp = bid % SFK_FIN_GROUPS, ngrp = nblk < SFK_FIN_GROUPS ? nblk : SFK_FIN_GROUPS;
+    const int members = (nblk - grp + SFK_FIN_GROUPS - 1) / SFK_FIN_GROUPS;
+    if (atomicAdd(&sync[SFK_FIN_LEAVE + grp * SFK_FIN_LINE], 1) == members - 1) {
+      if (atomicAdd(&sync[SFK_FIN_TOP], 1) == ngrp - 1) {         // everybody is past the wait
+        sync[SFK_FIN_DONE] = 0; sync[SFK_FIN_CLAIM] = 0; sync[SFK_FIN_TOP] = 0;
+        for (int i = 0; i < SFK_FIN_GROUPS; ++i) sync[SFK_FIN_LEAVE + i * SFK_FIN_LINE] = 0;
+        __threadfence();
+      }
     }
   }
 }
@@ -323,7 +363,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // group -- 1/16 of the bf16 map.  The backward of act(bn(y) + shortcut) reads it instead of the activation itself.
 // SUMS: the block also leaves the column sums of what it STORED as one partial row [c][2] = (sum a, 0) -- the fused block
 // tail takes g = 1^T a from these (sfk_bn_tail_fwd) instead of a constant-1 channel group beside every pixel.
-template <typename T, int RES, bool RELU, int NT, bool SUMS = false>
+template <typename T, int RES, bool RELU, int NT, bool SUMS = false, bool COH = false>
 __device__ __forceinline__ void bn_apply_body(FM y, FM res, FM out, int64_t pixels, int c,
                                               const float* scale, const float* shift,
                                               const float* rscale, const float* rshift, uint8_t* relu_bits,
@@ -337,8 +377,8 @@ __device__ __forceinline__ void bn_apply_body(FM y, FM res, FM out, int64_t pixe
   for (int i = 0; i < VEC; ++i) { asum[i] = 0.f; zsum[i] = 0.f; }
   if (cm.active) {
   float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
-  load_coef<VEC>(sc, scale, cm.cg);
-  load_coef<VEC>(sh, shift, cm.cg);
+  load_coef<VEC, COH>(sc, scale, cm.cg);
+  load_coef<VEC, COH>(sh, shift, cm.cg);
   if (RES == 2) {
     load_coef<VEC>(rsc, rscale, cm.cg);
     load_coef<VEC>(rsh, rshift, cm.cg);
@@ -403,8 +443,17 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(FM y, FM res, FM out,
                                                            const float* rscale, const float* rshift, uint8_t* relu_bits,
                                                            const FinK fin) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && fin.nbt) fin.nbt[0] += 1;
-  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_finalize_pair(fin, p); });
-  bn_apply_body<T, RES, RELU, NT, false>(y, res, out, pixels, c, fin.scale, fin.shift, rscale, rshift, relu_bits, nullptr);
+  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_finalize_pair<true>(fin, p); });
+  // The coefficients were written by OTHER workgroups of this launch.  An acquire fence per workgroup invalidates the L2
+  // thousands of times per launch (900 us against 40), device-coherent loads by every thread put 25 M requests on 128 addresses
+  // (210 us): ONE coherent read of the c x 2 floats per workgroup, through LDS (c <= SFK_FIN_MAX_C).
+  __shared__ float coefs[2 * SFK_FIN_MAX_C];
+  for (int i = threadIdx.x; i < c; i += 256) {
+    coefs[i] = __hip_atomic_load(fin.scale + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    coefs[SFK_FIN_MAX_C + i] = __hip_atomic_load(fin.shift + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  bn_apply_body<T, RES, RELU, NT, false>(y, res, out, pixels, c, coefs, coefs + SFK_FIN_MAX_C, rscale, rshift, relu_bits, nullptr);
   bn_fused_epilogue(fin.sync);
 }
 
@@ -493,6 +542,7 @@ struct BFinK {
   int* sync;
 };
 
+template <bool COH = false>
 __device__ __forceinline__ void bn_bwd_finalize_pair(const BFinK& f, int pair) {
   const int ch = pair * 2 + (threadIdx.x & 1);
   double s1, s2;
@@ -500,14 +550,14 @@ __device__ __forceinline__ void bn_bwd_finalize_pair(const BFinK& f, int pair) {
   if (threadIdx.x > 1) return;
   if (f.dgamma) f.dgamma[ch] += (float)s2;
   if (f.dbeta) f.dbeta[ch] += (float)s1;
-  f.coef[ch * 3 + 0] = f.gamma[ch] * f.invstd[ch];
-  f.coef[ch * 3 + 1] = (float)(s1 / f.count);
-  f.coef[ch * 3 + 2] = (float)(s2 / f.count);
+  st_coef<COH>(f.coef + ch * 3 + 0, f.gamma[ch] * f.invstd[ch]);
+  st_coef<COH>(f.coef + ch * 3 + 1, (float)(s1 / f.count));
+  st_coef<COH>(f.coef + ch * 3 + 2, (float)(s2 / f.count));
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BFinK f) { bn_bwd_finalize_pair(f, blockIdx.x); }
 
-template <typename T, int MASK, int NT>
+template <typename T, int MASK, int NT, bool COH = false>
 __device__ __forceinline__ void bn_bwd_apply_body(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
                                                   const float* mean, const float* invstd,
                                                   const float* scale, const float* shift,
@@ -526,9 +576,15 @@ __device__ __forceinline__ void bn_bwd_apply_body(FM da, FM y, FM msrc, FM dyo, 
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    c0[i] = coef[(cm.cg * VEC + i) * 3 + 0];
-    c1[i] = coef[(cm.cg * VEC + i) * 3 + 1];
-    c2[i] = coef[(cm.cg * VEC + i) * 3 + 2];
+    if (COH) {        // written by other workgroups of this launch (fused finalize): device-coherent loads, see load_coef
+      c0[i] = __hip_atomic_load(coef + (cm.cg * VEC + i) * 3 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c1[i] = __hip_atomic_load(coef + (cm.cg * VEC + i) * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c2[i] = __hip_atomic_load(coef + (cm.cg * VEC + i) * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      c0[i] = coef[(cm.cg * VEC + i) * 3 + 0];
+      c1[i] = coef[(cm.cg * VEC + i) * 3 + 1];
+      c2[i] = coef[(cm.cg * VEC + i) * 3 + 2];
+    }
   }
   const T* dap = static_cast<const T*>(da.p) + da.off + cm.cg * VEC;
   const T* yp = static_cast<const T*>(y.p) + y.off + cm.cg * VEC;
@@ -584,8 +640,11 @@ template <typename T, int MASK, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(FM da, FM y, FM msrc, FM dyo, int64_t pixels, int c,
                                                                const float* mean, const float* scale, const float* shift,
                                                                const BFinK fin) {
-  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_bwd_finalize_pair(fin, p); });
-  bn_bwd_apply_body<T, MASK, NT>(da, y, msrc, dyo, pixels, c, mean, fin.invstd, scale, shift, fin.coef);
+  bn_fused_prologue(fin.sync, fin.c / 2, [&](int p) { bn_bwd_finalize_pair<true>(fin, p); });
+  __shared__ float coefs[3 * SFK_FIN_MAX_C];            // one coherent read of the c x 3 coefficients per workgroup (see bn_apply_fin_kernel)
+  for (int i = threadIdx.x; i < 3 * c; i += 256) coefs[i] = __hip_atomic_load(fin.coef + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  bn_bwd_apply_body<T, MASK, NT>(da, y, msrc, dyo, pixels, c, mean, fin.invstd, scale, shift, coefs);
   bn_fused_epilogue(fin.sync);
 }
 
@@ -854,7 +913,7 @@ extern "C" int sfk_bn_finalize_apply(const float* partials, int32_t nparts, int6
   if (!sfk_fmap_ok(out) || !same_shape(y, out)) return SFK_ERR_INVALID;
   if (res && (!sfk_fmap_ok(res) || !same_shape(y, res))) return SFK_ERR_INVALID;
   if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res)) return SFK_ERR_INVALID;
-  if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res)) || (y->c & 1)) return SFK_ERR_UNSUPPORTED;
+  if (!sfk_fmap_vec_ok(y) || !sfk_fmap_vec_ok(out) || (res && !sfk_fmap_vec_ok(res)) || (y->c & 1) || y->c > SFK_FIN_MAX_C) return SFK_ERR_UNSUPPORTED;
   if (((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) || (((uintptr_t)sync) & 3)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rows = nparts;
@@ -1009,7 +1068,7 @@ extern "C" int sfk_bn_bwd_finalize_apply(const float* partials, int32_t nparts, 
   const int st = check_bwd(da, y, mask_src, mean, invstd, scale, shift, relu);
   if (st != SFK_OK) return st;
   if (!partials || nparts <= 0 || count <= 0 || !gamma || !coef || !sync || !sfk_fmap_ok(dy) || !same_shape(da, dy)) return SFK_ERR_INVALID;
-  if (!sfk_fmap_vec_ok(dy) || (y->c & 1)) return SFK_ERR_UNSUPPORTED;
+  if (!sfk_fmap_vec_ok(dy) || (y->c & 1) || y->c > SFK_FIN_MAX_C) return SFK_ERR_UNSUPPORTED;
   if (((((uintptr_t)partials) | ((uintptr_t)workspace)) & 15) || (((uintptr_t)sync) & 3)) return SFK_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rows = nparts;

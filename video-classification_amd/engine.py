@@ -149,7 +149,10 @@ class EngineOptions:
     trunk_priority: bool = True        # the trunk lane on a high-priority HIP stream (TrainStep)
     mfma_wgrad_trunk: bool = False     # MFMA-bound filter gradients on the pathway's own lane, directly behind their data gradient
     dist_wgrad_one_lane: bool = True   # world > 1: all filter gradients on ONE lane, the collective's stream is the fourth queue
-    fuse_finalize: bool = True         # BatchNorm finalize as the prologue of its bn_apply / bn_bwd_apply launch (sfk_bn_finalize_apply)
+    fuse_finalize: bool = False        # BatchNorm finalize as the prologue of its bn_apply / bn_bwd_apply launch (sfk_bn_finalize_apply):
+                                       # bit-identical, 5 us per launch alone -- and 27.7 -> 27.9 .. 28.1 ms in the step (waiting workgroups
+                                       # hold CUs the other lanes would use): off
+    fuse_finalize_max_c: int = 64      # ... for BatchNorms of at most this many channels (the pairs are claimed through one counter)
     lane_cus: str = ""                 # EXPERIMENT: CUs the side lanes may use, "fast,wgrad_slow,wgrad_fast" (0 / empty = all): the
                                        # side streams are created with hipExtStreamCreateWithCUMask (eager schedule only)
     ablate_kinds: frozenset = frozenset()
@@ -161,7 +164,8 @@ class EngineOptions:
             "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"),
             "SFK_SPLIT_ADAM": ("split_adam", "!0"), "SFK_TRUNK_PRIO": ("trunk_priority", "!0"),
             "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0"),
-            "SFK_LANE_CUS": ("lane_cus", "s"), "SFK_FUSE_FIN": ("fuse_finalize", "!0")}
+            "SFK_LANE_CUS": ("lane_cus", "s"), "SFK_FUSE_FIN": ("fuse_finalize", "!0"),
+            "SFK_FUSE_FIN_MAXC": ("fuse_finalize_max_c", "i")}
 
     @classmethod
     def from_env(cls, env=None) -> "EngineOptions":
@@ -489,9 +493,9 @@ class Engine:
             stats, mt = self._conv(pl, L, x, y, f"stats.{tag}")
             mean = self._buf(f"mean.{tag}", L.c, torch.float32)
             invstd = self._buf(f"invstd.{tag}", L.c, torch.float32)
-            if defer and self.options.fuse_finalize and hasattr(self.be, "bn_finalize_apply"):
+            if defer and self.options.fuse_finalize and L.c <= min(512, self.options.fuse_finalize_max_c) and hasattr(self.be, "bn_finalize_apply"):
                 self._pending_fin[id(scale)] = (stats, mt, y.pixels, gamma, beta, self.spec.bn_eps, self.spec.bn_momentum, L.rm, L.rv,
-                                                L.nbt, mean, invstd, self._fold_ws(tag, L.c), self._buf(f"finsync.{tag}", 2, torch.int32))
+                                                L.nbt, mean, invstd, self._fold_ws(tag, L.c), self._buf(f"finsync.{tag}", 2144, torch.int32))
             else:
                 pl.fwd.append(self.be.bn_finalize(stats, mt, L.c, y.pixels, gamma, beta, self.spec.bn_eps,
                                                   self.spec.bn_momentum, L.rm, L.rv, L.nbt, mean, invstd, scale, shift,
@@ -537,10 +541,10 @@ class Engine:
             pl.bwd.append(run, kind="bn_bwd_reduce", layer=L.cb.norm_key,
                           bytes=el * (2 + (1 if mask_src is not None else 0) + (1 if dz_inplace else 0))
                           + (rec.y.pixels * L.c // self.kvec if bits is not None else 0))
-        if self.options.fuse_finalize and hasattr(self.be, "bn_bwd_finalize_apply"):
+        if self.options.fuse_finalize and L.c <= min(512, self.options.fuse_finalize_max_c) and hasattr(self.be, "bn_bwd_finalize_apply"):
             # the finalize rides the apply launch as its prologue (sfk_bn_bwd_finalize_apply): dgamma / dbeta are complete behind it
             fin = (parts, np_, rec.y.pixels, self._pslice(L.g_off, L.c), self._gslice(L.g_off, L.c), self._gslice(L.b_off, L.c), coef,
-                   self._fold_ws(tag, L.c), self._buf(f"bfinsync.{tag}", 2, torch.int32))
+                   self._fold_ws(tag, L.c), self._buf(f"bfinsync.{tag}", 2144, torch.int32))
             if dz_inplace:   # the mask is already applied to da
                 run, nb = self.be.bn_bwd_finalize_apply(*fin, da, rec.y, None, rec.mean, rec.invstd, rec.scale, rec.shift, False, dy), 3
             else:
