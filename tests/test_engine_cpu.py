@@ -397,3 +397,26 @@ def test_res3d_train_step_k_steps_match_oracle():
     losses, upd = run_k_steps(om, m, res3d_input(), torch.tensor([2, 5]), k=3, lr=2e-4,
                               oracle_step=oracle_res3d_train_step)
     assert_k_step_parity(losses, upd, 2e-4, 3)
+
+
+def test_engine_options_defaults_env_mapping_and_no_environment_reads(monkeypatch):
+    """EngineOptions: the product defaults are the measured best (nothing experimental on), from_env maps every documented SFK_*
+    variable onto exactly one field with the right type, and Engine() itself never looks at the environment."""
+    import dataclasses
+    from video_classification_amd.engine import Engine, EngineOptions
+    d = EngineOptions()
+    assert d.fuse_finalize is False and d.lane_cus == "" and d.mfma_wgrad_trunk is False and d.ablate_kinds == frozenset()
+    assert d.non_default() == {}
+    fields = {f.name for f in dataclasses.fields(EngineOptions)}
+    assert {fld for fld, _ in EngineOptions._ENV.values()} <= fields
+    assert len({fld for fld, _ in EngineOptions._ENV.values()}) == len(EngineOptions._ENV)          # one variable per field
+    env = {"SFK_FUSE_FIN": "1", "SFK_FUSE_FIN_MAXC": "128", "SFK_WGRAD_LANES": "2", "SFK_SHORTCUT_LANE": "b", "SFK_TAIL": "0",
+           "SFK_LANE_CUS": "0,128,-128", "SFK_UNRELATED": "7"}
+    o = EngineOptions.from_env(env)
+    assert o.non_default() == {"fuse_finalize": True, "fuse_finalize_max_c": 128, "wgrad_lanes": 2, "shortcut_lane": "b",
+                               "fuse_tail": False, "lane_cus": "0,128,-128"}
+    # an Engine built without options ignores the same variables in the process environment
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    eng = Engine(arch.ref_spec(7, depth=18), dtype=torch.float32, device="cpu", backend=EmuBackend())
+    assert eng.options.non_default() == {}
