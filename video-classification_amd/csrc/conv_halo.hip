@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const ConvK k, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int b0 = blockIdx.x;
+  // XCD-aware band order (workgroups b, b + 8, ... share an L2): neighbouring bands share their halo rows
+  const int b0 = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   if (b0 >= nbands) return;
   const __amdgpu_buffer_rsrc_t xrs = sfk_make_rsrc(k.x, k.xbytes);
   auto fsw = [](int q) { return ((q >> 1) & 3) << 1; };

@@ -751,7 +751,10 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_v4_kernel(const StemK k, int 
   const int tpairs = (k.t_log + 1) / 2;
   const int tiles_h2 = (k.ho + H2_ROWS - 1) / H2_ROWS;
   H2Unit u;
-  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+  // XCD-aware order: workgroups b, b + 8, ... share an L2, so consecutive LOGICAL ids -- neighbouring tiles and temporal chunks,
+  // which read overlapping patch rows / columns / frames -- go to one XCD (round-robin units fetched 4.4 x the clip from HBM)
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  for (int unit = lb; unit < nunits; unit += gridDim.x) {
     u.set(k, unit, pairs_per_unit, tchunks, tiles_h2, tpairs);
     const int n = u.n, p0 = u.p0, p1 = u.p1;
     const int ho0 = u.th2 * H2_ROWS, wo0 = u.tw * TS;
@@ -907,7 +910,10 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_s4_kernel(const StemK k, int 
   const int tpairs = (k.t_log + 1) / 2;
   const int tiles_h2 = (k.ho + H2_ROWS - 1) / H2_ROWS;
   H2Unit u;
-  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+  // XCD-aware order: workgroups b, b + 8, ... share an L2, so consecutive LOGICAL ids -- neighbouring tiles and temporal chunks,
+  // which read overlapping patch rows / columns / frames -- go to one XCD (round-robin units fetched 4.4 x the clip from HBM)
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  for (int unit = lb; unit < nunits; unit += gridDim.x) {
     u.set(k, unit, pairs_per_unit, tchunks, tiles_h2, tpairs);
     const int n = u.n, p0 = u.p0, p1 = u.p1;                 // input = output pairs p0 .. p1 - 1
     const int ho0 = u.th2 * H2_ROWS, wo0 = u.tw * TS;
@@ -1051,7 +1057,10 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_v2_kernel(const StemK k) {
   char* dyt = smem + CIN * PLANE;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int item0 = blockIdx.x * k.tiles_per_block;
+  // XCD-aware ranges (workgroups b, b + 8, ... share an L2): consecutive LOGICAL workgroups walk neighbouring frames of one clip
+  // at the same tile at the same time, and the five input frames that see one dY tile then find it in their XCD's L2
+  const int lb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int item0 = lb * k.tiles_per_block;
   const int item1 = min(item0 + k.tiles_per_block, k.ntiles);
   if (item0 >= item1) return;
   const bf16_t* src = static_cast<const bf16_t*>(k.src);
@@ -1338,6 +1347,7 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
     if (blocks > k.ntiles) blocks = k.ntiles;
     k.tiles_per_block = (k.ntiles + blocks - 1) / blocks;
     blocks = (k.ntiles + k.tiles_per_block - 1) / k.tiles_per_block;
+    blocks = (blocks + 7) & ~7;                 // a multiple of 8 for the XCD-aware range order (surplus workgroups find no items)
     hipLaunchKernelGGL((stem_wgrad_v2_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, hs, k);
     SFK_CHECK_LAUNCH();
     return SFK_OK;
