@@ -523,7 +523,8 @@ typedef struct {
   int32_t stem_v3;            /* 3:    bit 0: the input-frame-stationary forward of the canonical fast stem (filter in registers, one LDS
                                          pixel run per three MFMAs, half tiles with two workgroups per CU: stem_fwd_v4_kernel);
                                          bit 1: the same machinery for the canonical slow stem (kt = 1, 64 channels:
-                                         stem_fwd_s4_kernel)                                                               */
+                                         stem_fwd_s4_kernel); bit 2 (EXPERIMENT): whole frames per workgroup in the fast stem's
+                                         filter gradient                                                                   */
 } sfk_tuning;
 int sfk_default_tuning(sfk_tuning* out); /* out->struct_size must be set; fills every other field */
 int sfk_init(const sfk_tuning* t);       /* NULL = defaults */

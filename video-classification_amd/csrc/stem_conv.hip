@@ -1346,6 +1346,13 @@ extern "C" int sfk_stem_conv_wgrad(const sfk_stem_src* s, const sfk_fmap* dy, fl
     int blocks = 256 * 3;                       // 3 resident workgroups per CU (LDS 44 KB each)
     if (blocks > k.ntiles) blocks = k.ntiles;
     k.tiles_per_block = (k.ntiles + blocks - 1) / blocks;
+    if (sfk_tune().stem_v3 & 4) {
+      // whole FRAMES per workgroup: neighbouring workgroups (= neighbouring frames of a clip, one XCD) are then at the same tile
+      // at the same time, and the kt input frames that read one dY tile find it in the L2 (ranges of 66 tiles drift by 17 tiles
+      // per workgroup: 2.04 GB from HBM for 0.51 GB of operands)
+      const int tpf = k.tiles_h * k.tiles_w;
+      k.tiles_per_block = (k.tiles_per_block + tpf - 1) / tpf * tpf;
+    }
     blocks = (k.ntiles + k.tiles_per_block - 1) / k.tiles_per_block;
     blocks = (blocks + 7) & ~7;                 // a multiple of 8 for the XCD-aware range order (surplus workgroups find no items)
     hipLaunchKernelGGL((stem_wgrad_v2_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, hs, k);
