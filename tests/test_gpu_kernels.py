@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from emu_backend import EmuBackend
-from helpers import rel_err
+from helpers import rel_err, rel_l2
 from video_classification_amd._lib import ConvPass, FMap, StemSrc, WgradPass, stem_kp
 from video_classification_amd.plan import ConvGeom, dgrad_passes, fwd_pass, wgrad_taps
 
@@ -352,6 +352,38 @@ def test_conv_filter_gradient_band_bf16(hip, case):
     assert float((wp.dw.cpu() - dwc).abs().max()) < 2e-5 * scale + 1e-4
 
 
+@pytest.mark.parametrize("cin,dims", [(64, (32, 8, 56, 56)), (128, (32, 8, 28, 28))], ids=["res2", "res3"])
+def test_conv_filter_gradient_band_at_the_metric_size(hip, cin, dims):
+    """the band kernel at the benchmark's own layer sizes (slow res2 / res3 conv_b, batch 32): no CPU restatement finishes there, so
+    the check is a property -- the SAME gradient out of two independent kernels (LDS bands + ordered partial sums against the
+    implicit GEMM with atomics: different staging, different K order, different reduction), linearity in dY (dW(2 dY) = 2 dW(dY)
+    bit for bit: powers of two commute with every rounding) and a repeat that is bit-identical."""
+    from video_classification_amd._lib import tuning
+    if not (tuning().wgrad_band & (1 if cin == 64 else 2)):
+        pytest.skip("this width of the LDS-band filter-gradient kernel is off in this process (SFK_WGBAND)")
+    n, t, h, w = dims
+    g = ConvGeom(cin, cin, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = FMap((torch.randn(n * t * h * w * cin, device=DEV, generator=gen)).to(torch.bfloat16), n, t, h, w, cin)
+    dy = FMap((torch.randn(n * t * h * w * cin, device=DEV, generator=gen) * 0.05).to(torch.bfloat16), n, t, h, w, cin)
+    dy2 = FMap((dy.buf.float() * 2).to(torch.bfloat16), n, t, h, w, cin)
+    numel = cin * g.wtaps * cin
+
+    def grad(dy_, workspace):
+        wp = WgradPass(x, dy_, g.s, list(wgrad_taps(g)), torch.zeros(numel, device=DEV), g.wtaps, cin, cin)
+        if workspace:
+            wp.workspace = torch.empty(hip.conv_wgrad_workspace_bytes(wp) // 4 + 4, device=DEV)
+        hip.conv_wgrad(wp)(stream())
+        torch.cuda.synchronize()
+        return wp.dw
+    band, band_again, band2, ring = grad(dy, True), grad(dy, True), grad(dy2, True), grad(dy, False)
+    assert torch.equal(band, band_again)
+    assert torch.equal(band2, band * 2)
+    scale = float(ring.abs().max())
+    assert float((band - ring).abs().max()) < 2e-4 * scale, (float((band - ring).abs().max()), scale)
+    assert rel_l2(band.cpu(), ring.cpu()) < 2e-5
+
+
 HALO_CASES = [
     # cin = cout, (n, t, h, w)            conv_halo.hip: the (1,3,3) stride-1 conv of slow res2 out of an LDS band, filter in registers
     (64, (2, 3, 56, 56)),       # 84 bands: one per workgroup
@@ -532,6 +564,46 @@ def test_stem_conv_slow_register_filter_bf16(hip, case):
     assert torch.all(yg.buf.cpu().float().view(-1, cout + 8)[:, :8] == 2.0)
     assert torch.isfinite(stg).all()
     assert rel_err(stg.cpu().view(mt, cout, 2).sum(0), stc.view(mt, cout, 2).sum(0)) < 1e-4   # (the restatement's rows are not tiles)
+
+
+@pytest.mark.parametrize("which", ["fast", "slow"])
+def test_stem_forward_at_the_metric_size(hip, which):
+    """the register-filter stem kernels at the benchmark's clip (32 x 3 x T x 224 x 224): the same convolution out of two
+    independent kernels -- the frame-stationary half-tile kernel on the bf16 clip against the generic patch kernel on an fp32
+    copy of the same values (another staging, another K order) -- plus exact linearity in the filter (2 w -> 2 y bit for bit) and
+    BatchNorm partial sums that add up to the sums of the stored map."""
+    from video_classification_amd._lib import tuning
+    if not (tuning().stem_v3 & (1 if which == "fast" else 2)):
+        pytest.skip("this stem's register-filter kernel is off in this process (SFK_STEM3)")
+    n, h, w = 32, 224, 224
+    t, kt, cout = (32, 5, 8) if which == "fast" else (8, 1, 64)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    clip = torch.randn(n, 3, t, h, w, device=DEV, generator=gen).to(torch.bfloat16)
+    kp = stem_kp(3, kt)
+    wref = torch.randn(cout, 3, kt, 7, 7, generator=torch.Generator().manual_seed(2)) * (3 * kt * 49) ** -0.5
+    wl = torch.nn.functional.pad(wref.permute(0, 2, 1, 3, 4), (0, 1)).reshape(cout, kt * 3 * 56)
+    wl = torch.nn.functional.pad(wl, (0, kp - wl.shape[1])).reshape(-1).to(torch.bfloat16).to(DEV)
+    ho, wo = h // 2, w // 2
+
+    def fwd(src, filt):
+        y = FMap(torch.zeros(n * t * ho * wo * cout, dtype=torch.bfloat16, device=DEV), n, t, ho, wo, cout)
+        ssrc = StemSrc(src, None, kt)
+        mt = hip.stem_conv_tiles(ssrc, y)
+        stats = torch.full((mt * cout * 2,), float("nan"), device=DEV)
+        hip.stem_conv_fwd(ssrc, filt, y, stats)(stream())
+        torch.cuda.synchronize()
+        return y.buf, stats.view(mt, cout, 2)
+    y1, st1 = fwd(clip, wl)
+    y2, _ = fwd(clip, (wl.float() * 2).to(torch.bfloat16))
+    assert torch.equal(y2.view(torch.int16), (y1.float() * 2).to(torch.bfloat16).view(torch.int16))
+    yg, stg = fwd(clip.float(), wl)                     # fp32 source: the generic kernel
+    assert rel_l2(y1.float().cpu(), yg.float().cpu()) < 2e-3
+    assert torch.isfinite(st1).all()
+    v = y1.float().view(-1, cout)
+    # (the kernel sums the fp32 accumulators, the check sums the bf16-rounded map: 2^-9 relative per element, far less in the sum)
+    assert rel_err(st1.sum(0)[:, 0].cpu(), v.sum(0).cpu()) < 2e-3
+    assert rel_err(st1.sum(0)[:, 1].cpu(), (v * v).sum(0).cpu()) < 2e-3
+    assert rel_err(st1.sum(0).cpu(), stg.sum(0).cpu()) < 1e-3
 
 
 @pytest.mark.parametrize("c,nparts", [(8, 50176), (256, 3136), (80, 129), (2048, 300), (64, 128)],
