@@ -566,6 +566,43 @@ def test_stem_conv_slow_register_filter_bf16(hip, case):
     assert rel_err(stg.cpu().view(mt, cout, 2).sum(0), stc.view(mt, cout, 2).sum(0)) < 1e-4   # (the restatement's rows are not tiles)
 
 
+def test_conv_halo_at_the_metric_size(hip):
+    """the LDS-band 3 x 3 kernel on slow res2 conv_b at batch 32: against the implicit GEMM on the same operands (the `+=` form of
+    the call into a zeroed map is not eligible for the band kernel and takes the implicit-GEMM family), exact linearity in the
+    filter and a bit-identical repeat; the BatchNorm partial rows add up to the sums of the stored map."""
+    from video_classification_amd._lib import tuning
+    if not tuning().igemm_halo:
+        pytest.skip("the LDS-band kernel is off in this process (SFK_HALO=0)")
+    n, t, h, w, c = 32, 8, 56, 56, 64
+    g = ConvGeom(c, c, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x = FMap(torch.randn(n * t * h * w * c, device=DEV, generator=gen).to(torch.bfloat16), n, t, h, w, c)
+    wt = (torch.randn(c * g.wtaps * c, device=DEV, generator=gen) * (g.wtaps * c) ** -0.5).to(torch.bfloat16)
+    sp = fwd_pass(g, (t, h, w))
+
+    def run(filt, accumulate, stats):
+        y = FMap(torch.zeros(n * t * h * w * c, dtype=torch.bfloat16, device=DEV), n, t, h, w, c)
+        ps = ConvPass(x, y, sp.rows, sp.gs, sp.os, sp.oo, list(sp.taps), filt, g.wtaps, c, c, accumulate=accumulate)
+        fam = hip.conv_family(ps)
+        if stats:
+            ps.stats = torch.full((hip.conv_igemm_mtiles(ps) * c * 2,), float("nan"), device=DEV)
+        hip.conv_igemm(ps)(stream())
+        torch.cuda.synchronize()
+        return y.buf, fam, ps.stats
+    ya, fam_a, st = run(wt, False, True)
+    yb, fam_b, _ = run(wt, False, False)
+    y2, _, _ = run((wt.float() * 2).to(torch.bfloat16), False, False)
+    yg, fam_g, _ = run(wt, True, False)
+    assert fam_a == 5 and fam_b == 5 and fam_g != 5                    # band kernel / implicit GEMM
+    assert torch.equal(ya, yb)
+    assert torch.equal(y2.view(torch.int16), (ya.float() * 2).to(torch.bfloat16).view(torch.int16))
+    assert rel_l2(ya.float().cpu(), yg.float().cpu()) < 2e-3
+    v = ya.float().view(-1, c)
+    stv = st.view(-1, c, 2)
+    assert torch.isfinite(stv).all()
+    assert rel_err(stv.sum(0)[:, 0].cpu(), v.sum(0).cpu()) < 2e-3 and rel_err(stv.sum(0)[:, 1].cpu(), (v * v).sum(0).cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("which", ["fast", "slow"])
 def test_stem_forward_at_the_metric_size(hip, which):
     """the register-filter stem kernels at the benchmark's clip (32 x 3 x T x 224 x 224): the same convolution out of two
