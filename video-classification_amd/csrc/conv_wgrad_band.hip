@@ -1,5 +1,6 @@
 // conv_wgrad_band: the filter gradient of the (1,3,3) stride-1 "same" convs whose whole dW fits the accumulators of ONE
-// workgroup -- slow res2 conv_b (64 -> 64 over 56 x 56 frames): dW = 64 x 576 fp32 = 144 KB.
+// workgroup -- slow res2 conv_b (64 -> 64 over 56 x 56 frames): dW = 64 x 576 fp32 = 144 KB -- or of two: slow res3 conv_b
+// (128 -> 128 over 28 x 28), one workgroup per input-channel half (128 x 576 each; BandCfg<28, 128, 128>, described at the end).
 //
 //   dW[co][(dh, dw), ci] = sum over pixels  dY[pixel][co] * X[pixel + (dh, dw)][ci]
 //
@@ -23,6 +24,13 @@
 // SAME outputs and alternate K-steps (global K-step counter parity), so that one multiplies (36 MFMAs at raised priority)
 // while the other issues its 26 transposed reads; their sums meet through LDS once, at the end.  The workgroup's partial dW
 // goes to the caller's workspace, band_reduce_kernel adds the workgroups' partials in a fixed order (deterministic).
+// The next band's LDS-DMA instructions are issued a few per K-step behind the fragment reads; the MFMA priority is 2 for kg = 0
+// and 1 for kg = 1 (equal priorities interleave the two waves' MFMA blocks, both finish together and then both sit in their
+// reads).  Band order is XCD-aware (neighbouring bands share halo rows: HBM reads = 1.0 x the operands, no LDS bank conflicts).
+//
+// 128 channels (BandCfg<28, 128, 128>): a band of 4 x 28 = 112 pixels = 3.5 K-steps (the last one half-filled: zero fragments),
+// a unit = (band, input-channel half); kg picks the wave's four output-channel fragments (8 dY planes), every wave runs every
+// K-step and its address registers move to the other buffer after each band; no exchange at the end.
 #include "conv_wgrad_common.h"
 
 #ifndef SFK_BAND_EXP
