@@ -94,6 +94,12 @@ class OpList(list):
     def sync(self, lane: int, on: int):
         self.append(Wait(lane, on))
 
+    def insert_at(self, i: int, op, lane: int, **meta):
+        """op (or a Wait) into position i of the issue order"""
+        super().insert(i, op)
+        self.meta.insert(i, meta or None)
+        self.lane.insert(i, op.lane if isinstance(op, Wait) else lane)
+
 
 class Plan:
     def __init__(self):
@@ -145,6 +151,7 @@ class EngineOptions:
     fuse_tail_dg: bool = True          # R and the first dgrad pass of the tail backward in one kernel
     tail_r_lane: int = 0               # R = dz^T a beside the first dgrad pass: 0 pathway lane, 2 filter-gradient lane, 4 own lanes
     split_refresh: bool = True         # filter refresh: stems on the trunk, the rest on the idle filter-gradient lane
+    refresh_behind_stems: bool = True  # ... issued BEHIND the two stem convs (it waits for both) instead of beside them
     split_adam: bool = True            # Adam beside the last kernel of the step (TrainStep)
     trunk_priority: bool = True        # the trunk lane on a high-priority HIP stream (TrainStep)
     mfma_wgrad_trunk: bool = False     # MFMA-bound filter gradients on the pathway's own lane, directly behind their data gradient
@@ -161,7 +168,7 @@ class EngineOptions:
             "SFK_WGRAD_LANES": ("wgrad_lanes", "i"), "SFK_RELU_BITS": ("relu_bits", "!0"), "SFK_RELU_OUT": ("relu_out_mask", "!0"),
             "SFK_WGWS": ("deterministic_wgrad", "1"), "SFK_TAIL": ("fuse_tail", "!0"), "SFK_TAIL_MINC": ("tail_min_c", "i"),
             "SFK_TAIL_MAXC": ("tail_max_c", "i"), "SFK_STEM_TAIL": ("fuse_stem_tail", "!0"), "SFK_TAIL_DG": ("fuse_tail_dg", "!0"),
-            "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"),
+            "SFK_TAIL_RLANE": ("tail_r_lane", "i"), "SFK_SPLIT_REFRESH": ("split_refresh", "!0"), "SFK_REFRESH_BEHIND": ("refresh_behind_stems", "!0"),
             "SFK_SPLIT_ADAM": ("split_adam", "!0"), "SFK_TRUNK_PRIO": ("trunk_priority", "!0"),
             "SFK_WGRAD_TRUNK": ("mfma_wgrad_trunk", "1"), "SFK_DIST_ONE_LANE": ("dist_wgrad_one_lane", "!0"),
             "SFK_LANE_CUS": ("lane_cus", "s"), "SFK_FUSE_FIN": ("fuse_finalize", "!0"),
@@ -1054,6 +1061,7 @@ class Engine:
         # the pathways wait for it before their first non-stem conv (the 110 us of the single launch sat in front of the step
         # with nothing to overlap them)
         refresh_lane = None
+        deferred_refresh = None
         if self.dtype != torch.float32 or train:
             s_ = self.S if self.dtype != torch.float32 else None
             ent = lambda Ls: [(L.w_off, L.eg.cout, L.eg.wtaps, L.eg.cin, L.needs_dgrad) for L in Ls]
@@ -1063,10 +1071,14 @@ class Engine:
             if split:
                 pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key in stem_keys])))
                 refresh_lane = 2
-                pl.fwd.sync(refresh_lane, 0)                  # after the previous step's optimiser (trunk order)
-                pl.fwd.cur_lane = refresh_lane
-                pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key not in stem_keys])))
-                pl.fwd.cur_lane = 0
+                rest_refresh = be.filter_refresh(self.P.data, s_, self.St, ent([L for L in self.layers if L.cb.conv_key not in stem_keys]))
+                if self.options.refresh_behind_stems:
+                    deferred_refresh = rest_refresh          # issued behind the stem convs, below
+                else:
+                    pl.fwd.sync(refresh_lane, 0)              # after the previous step's optimiser (trunk order)
+                    pl.fwd.cur_lane = refresh_lane
+                    pl.fwd.append(rest_refresh)
+                    pl.fwd.cur_lane = 0
             else:
                 pl.fwd.append(be.filter_refresh(self.P.data, s_, self.St if train else None, ent(self.layers)))
         if self._tailz["f"] is not None:
@@ -1101,6 +1113,16 @@ class Engine:
         if NP == 2:
             F_.cur_lane = 1
             stem_recs.append(self._stem_fwd(pl, 1, x_fast, None, xf, train))
+        if deferred_refresh is not None:
+            # The non-stem refresh (123 us, 0.27 GB) beside the stems slowed BOTH of them (stem class 0.56 -> 0.87 ms in the step):
+            # it now waits for the two stem convs -- a Wait right behind each conv in the issue order, not behind the stems'
+            # BatchNorm / pool kernels -- and runs on the filter-gradient lane under those; the pathways wait for it as before.
+            s0, s1 = pl.stem_state[0]["fwd_slot"], pl.stem_state[1]["fwd_slot"]
+            assert s0 < s1
+            F_.insert_at(s1 + 1, Wait(refresh_lane, 1), refresh_lane)      # (the later position first: s0 stays valid)
+            F_.insert_at(s1 + 2, deferred_refresh, refresh_lane)
+            F_.insert_at(s0 + 1, Wait(refresh_lane, 0), refresh_lane)
+            pl.stem_state[1]["fwd_slot"] = s1 + 1                          # the fast stem's conv moved down by that Wait
         fusion_recs = [None] * 4
         if refresh_lane is not None:                    # the non-stem filter copies are ready (split refresh, above)
             F_.sync(1, refresh_lane)
